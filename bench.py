@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py — Mray/s of the path-tracing hot path on the BASELINE cover scene.
+
+A step is one frame: one pass of the hot path (ray generation, ray-sphere list
+intersection, scatter, multi-sample accumulate, RGBA8 store) over the
+1200x800x100spp cover scene (~485 spheres, depth 50), synthetic scene from the
+shared counter RNG, inputs resident in HBM.  With --gpus N > 1 the SAME frame is
+row-tiled over N ranks (block-cyclic) and gathered to rank 0 over RCCL: total
+work is fixed, so scaling is "strong".
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector (= f32 MFMA rate)
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FLOPS_PER_TEST = 16             # oc 3, hb 5, cc 6, disc 2 (unit direction: a == 1)
+FLOPS_PER_SEGMENT_SHADE = 60
+
+WORKLOADS = {
+    # name: (scene, grid_half, width, height, spp, depth)
+    "cover_1200x800_100spp": ("cover", 11, 1200, 800, 100, 50),
+    "cover_1200x800_500spp": ("cover", 11, 1200, 800, 500, 50),
+    "three_400x225_100spp": ("three", 0, 400, 225, 100, 50),
+    "cover4096_3840x2160_1024spp": ("cover", 32, 3840, 2160, 1024, 50),
+    "cover_300x200_10spp": ("cover", 11, 300, 200, 10, 50),
+}
+
+
+def build_scene(V, scene, grid_half, w, h):
+    if scene == "three":
+        sph, mat = V.make_three_sphere_scene(False)
+        cam = V.camera_from_ubo(V.ubo_from_image(w, h))
+    else:
+        sph, mat = V.make_cover_scene(1, grid_half)
+        cam = V.make_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, w / h, 0.1, 10.0)
+    return sph, mat, cam
+
+
+def cpu_baseline(V, sph, mat, cam, w, h, spp, depth, chunk, target_s=15.0):
+    """Times the CPU oracle (kind "port": the reference has no CPU path) on a bounded sample:
+    every k-th row of the same frame, all host cores, sized for ~target_s seconds."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_bind
+    orc = oracle_bind.load()
+    cores = orc.num_procs()
+    # probe: 4 evenly spread rows
+    probe_rows = 4
+    stride = max(1, h // probe_rows)
+    prm = V.make_params(w, h, spp=spp, max_depth=depth, seed=1, chunk_spp=chunk, row_block=1,
+                        tile_rank=0, tile_count=stride)
+    t0 = time.perf_counter()
+    img, _ = orc.render(sph, mat, cam, prm)
+    probe_t = time.perf_counter() - t0
+    per_row = probe_t / max(1, img.shape[0])
+    rows = int(min(h, max(probe_rows, target_s / max(per_row, 1e-9))))
+    stride = max(1, h // rows)
+    prm = V.make_params(w, h, spp=spp, max_depth=depth, seed=1, chunk_spp=chunk, row_block=1,
+                        tile_rank=0, tile_count=stride)
+    t0 = time.perf_counter()
+    img, segs = orc.render(sph, mat, cam, prm)
+    dt = time.perf_counter() - t0
+    n_rows = img.shape[0]
+    return {
+        "value": n_rows * w * spp * depth / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+        "sample": f"every {stride}th row ({n_rows} of {h} rows) of the same frame at full spp/depth, "
+                  f"{dt:.1f} s, OpenMP dynamic over rows",
+        "segments_per_s": segs / dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cover_1200x800_100spp", choices=sorted(WORKLOADS))
+    ap.add_argument("--chunk-spp", type=int, default=10)
+    ap.add_argument("--row-block", type=int, default=4)
+    ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import vulkan_rtiow_amd as V
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus) and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        D = __import__("importlib").import_module("vulkan-rtiow_amd.dist")
+
+    scene, grid_half, w, h, spp, depth = WORKLOADS[args.workload]
+    sph, mat, cam = build_scene(V, scene, grid_half, w, h)
+    ctx = V.Context(local_rank)
+    ctx.set_scene(sph, mat)
+    prm = V.make_params(w, h, spp=spp, max_depth=depth, seed=1, chunk_spp=args.chunk_spp,
+                        quantiser=V.RT_QUANT_BOOK, row_block=args.row_block if world > 1 else 0,
+                        tile_rank=rank if world > 1 else 0, tile_count=world if world > 1 else 0,
+                        kernel=args.kernel)
+    rows = V.tile_row_count(h, prm.row_block, prm.tile_rank, prm.tile_count)
+    local = torch.zeros((rows, w), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.render_device(cam, prm, local.data_ptr(), w * 4, stream)
+        if world > 1:
+            return D.gather_frame(local, h, prm.row_block, rank, world)
+        return local
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    frame = None
+    for k in range(args.steps):
+        ev[k][0].record()                       # same stream the kernels are launched on
+        ctx.render_device(cam, prm, local.data_ptr(), w * 4, stream)
+        ev[k][1].record()
+        frame = D.gather_frame(local, h, prm.row_block, rank, world) if world > 1 else local
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    st = ctx.stats()
+
+    t = torch.tensor([elapsed, kernel_ms, float(st.segments)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, kernel_ms_max, segments = tmax[0].item(), tmax[1].item(), tsum[2].item()
+    else:
+        kernel_ms_max, segments = kernel_ms, float(st.segments)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        nominal = w * h * spp * depth
+        value = nominal / (elapsed / args.steps) / 1e6
+        n = len(sph)
+        # dominant kernel: the path-trace kernel of rank 0's tile (per launch)
+        flops = st.segments * (FLOPS_PER_TEST * n + FLOPS_PER_SEGMENT_SHADE)
+        achieved = flops / (kernel_ms * 1e-3) / 1e12
+        fb_bytes = st.bytes_written
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if world == 1 and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("workload") == args.workload:
+                traffic = tj.get("hbm_bytes_per_launch")
+        out = {
+            "metric": "Mray/s (w*h*spp*depth / s), cover scene 1200x800", "value": value, "unit": "Mray/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "spheres": n, "width": w, "height": h, "spp": spp,
+                       "max_depth": depth, "chunk_spp": args.chunk_spp, "seed": 1,
+                       "partition": (f"row-tiles block-cyclic x{args.row_block} over {world} GPUs + RCCL gather"
+                                     if world > 1 else "single GPU"),
+                       "segments_per_frame": int(segments), "segments_per_s": segments / (elapsed / args.steps),
+                       "sphere_tests_per_s": segments * n / (elapsed / args.steps),
+                       "kernel_ms_rank0": kernel_ms, "kernel_ms_max": kernel_ms_max},
+            "roofline": {
+                "bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": traffic,
+                "note": "fp32 vector-ALU bound (no dense contraction: MFMA unused by design); algorithmic "
+                        f"flops = segments*({FLOPS_PER_TEST}*N+{FLOPS_PER_SEGMENT_SHADE}), kernel time = HIP events "
+                        "on the launch stream over the timed steps",
+                "hbm_write": {"achieved": fb_bytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": fb_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "bytes_per_launch": fb_bytes},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(V, sph, mat, cam, w, h, spp, depth, args.chunk_spp, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,206 @@
+/*
+ * rtiow.h — C-ABI of the MI355X-native path tracer that replaces the compute
+ * dispatch of baeng72/Vulkan-RTIOW.
+ *
+ * The reference has no plugin/FFI API; its de-facto boundary is the compute
+ * dispatch block RTCHAP06/main.cpp:313-325 plus the two resources bound at
+ * RTCHAP06/main.cpp:127-151 (binding 0: rgba8 storage image, binding 1: the
+ * 20-byte camera UBO).  Every entry point below cites the reference interface
+ * it stands in for.  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * Conventions (mirroring Vulkan.h:111-133's caller-owned POD handles):
+ *   - every function returns an int status (RT_OK == 0) and never aborts
+ *     (the reference asserts: Vulkan.cpp:60-62; a C ABI cannot);
+ *   - a context belongs to one GPU and one host thread at a time;
+ *   - the framebuffer is W*H packed RGBA8 (bytes R,G,B,A; A == 0 exactly as
+ *     imageStore(vec4(color,0.0)) writes it, raytrace06.comp:66), row 0 = the
+ *     BOTTOM of the scene (raytrace06.comp:58; the display flips it in
+ *     rt.frag:8, and so does rtWritePPM).
+ */
+#ifndef RTIOW_H
+#define RTIOW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTIOW_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------ */
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = 1,   /* bad argument (null pointer, zero size, bad mode) */
+    RT_ERR_NO_DEVICE = 2, /* no such GPU / HIP runtime unusable                */
+    RT_ERR_HIP = 3,       /* a HIP call failed; see rtGetLastError            */
+    RT_ERR_NOMEM = 4,
+    RT_ERR_STATE = 5,     /* e.g. PATH render before rtSetScene               */
+    RT_ERR_IO = 6
+};
+
+/* ---- render modes ------------------------------------------------------ */
+enum {
+    RT_MODE_CH05 = 5,  /* RTCHAP05/RTCHAP05/Shaders/raytrace05.comp:21-61: flat red sphere   */
+    RT_MODE_CH06 = 6,  /* RTCHAP06/Shaders/raytrace06.comp:21-66: normal-shaded sphere       */
+    RT_MODE_PATH = 13  /* sphere list + lambertian/metal/dielectric + spp accumulate
+                          (BUILD-SPEC: not in the reference)          */
+};
+
+/* ---- quantisers (hard part 5) ---------------------- */
+enum {
+    RT_QUANT_UNORM8 = 0, /* clamp[0,1]*255 round-half-up: rgba8 imageStore, raytrace06.comp:3,66 */
+    RT_QUANT_BOOK = 1    /* (int)(256*clamp(x,0,0.999)): the RTIOW book's write_color            */
+};
+
+/* ---- material kinds ---------------------------------------------------- */
+enum { RT_MAT_LAMBERTIAN = 0, RT_MAT_METAL = 1, RT_MAT_DIELECTRIC = 2 };
+
+/* The reference's camera UBO, bit-compatible (raytrace06.comp:4-10; host
+ * mirror RTCHAP06/main.cpp:109-120): five packed floats, sizeof == 20. */
+typedef struct RtUbo5 {
+    float imageWidth;
+    float imageHeight;
+    float viewportWidth;
+    float viewportHeight;
+    float focalLength;
+} RtUbo5;
+
+/* One sphere of the hittable list (16 B).  radius may be negative (hollow
+ * glass: the outward normal flips). */
+typedef struct RtSphere {
+    float cx, cy, cz;
+    float radius;
+} RtSphere;
+
+/* One material per sphere (32 B). */
+typedef struct RtMaterial {
+    uint32_t kind;   /* RT_MAT_*                                   */
+    float albedo[3]; /* lambertian, metal                          */
+    float fuzz;      /* metal, clamped to [0,1] by rtSetScene      */
+    float ior;       /* dielectric                                 */
+    uint32_t pad[2];
+} RtMaterial;
+
+/* Positionable thin-lens camera in derived form.
+ * Fill it with rtMakeCamera or rtCameraFromUbo. */
+typedef struct RtCamera {
+    float origin[3];
+    float lower_left[3];
+    float horizontal[3];
+    float vertical[3];
+    float u[3], v[3], w[3];
+    float lens_radius;
+} RtCamera;
+
+/* Per-render parameters. */
+typedef struct RtParams {
+    uint32_t width;      /* full image width                                        */
+    uint32_t height;     /* full image height                                       */
+    uint32_t spp;        /* samples per pixel (PATH)                                */
+    uint32_t max_depth;  /* bounce limit (PATH)                                     */
+    uint32_t seed;       /* RNG seed (PATH)                                         */
+    uint32_t mode;       /* RT_MODE_*                                               */
+    uint32_t quantiser;  /* RT_QUANT_*                                              */
+    uint32_t chunk_spp;  /* samples summed sequentially per partial sum; the pixel
+                            is the sequential sum of its partial sums.  0 or >= spp
+                            means one chunk (the book's plain loop).               */
+    /* Row tiling across GPUs: this call renders the rows r with
+     * (r / row_block) % tile_count == tile_rank, packed in ascending order.
+     * tile_count == 0 or 1 renders the whole image. */
+    uint32_t row_block;
+    uint32_t tile_rank;
+    uint32_t tile_count;
+    uint32_t kernel;     /* 0 = default; other values select kernel variants (rtiow_amd
+                            tuning/ablation only — results are identical by contract) */
+} RtParams;
+
+typedef struct RtStats {
+    double kernel_ms;        /* HIP-event time of the device work of the last render      */
+    uint64_t paths;          /* camera paths started                                      */
+    uint64_t segments;       /* ray segments traced (each tests every sphere)             */
+    uint64_t sphere_tests;   /* segments * n_spheres                                      */
+    uint64_t bytes_written;  /* algorithmic framebuffer bytes of the last render          */
+    uint32_t rows_rendered;
+    uint32_t n_spheres;
+} RtStats;
+
+typedef struct RtContext RtContext;
+
+/* ---- device lifetime: replaces initInstance/choosePhysicalDevice/initDevice
+ *      (RTCHAP06/Vulkan.cpp:46-153) and their cleanup* twins ---------------- */
+int rtCreate(int device_id, RtContext** out_ctx);
+int rtDestroy(RtContext* ctx);
+const char* rtGetLastError(const RtContext* ctx); /* ctx may be NULL: global error */
+int rtAbiVersion(void);
+
+/* ---- scene upload: BUILD-SPEC extension of the descriptor writes at
+ *      RTCHAP06/main.cpp:140-151 (the reference binds no scene buffer) ----- */
+int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materials,
+               uint32_t n_spheres);
+
+/* ---- the dispatch: replaces vkCmdDispatch + vkQueueSubmit + fence wait
+ *      (RTCHAP06/main.cpp:313-325).  dst receives rtTileRowCount(...) rows of
+ *      dst_pitch bytes each (dst_pitch >= 4*width, multiple of 4).
+ *      dst_is_device != 0: dst is a device pointer on ctx's GPU and the work
+ *      is enqueued on `stream` (a hipStream_t, NULL = the context's stream)
+ *      without a host sync; otherwise dst is host memory and the call returns
+ *      when the frame is in it (fixing the unsynchronised compute->graphics
+ *      hazard of main.cpp:324 vs :354). */
+int rtRender(RtContext* ctx, const RtCamera* cam, const RtParams* params, void* dst,
+             size_t dst_pitch, int dst_is_device, void* stream);
+
+/* The reference's own call shape: 20-byte UBO in, image out
+ * (RTCHAP06/main.cpp:109-124 + :313-325).  mode is RT_MODE_CH05/CH06. */
+int rtRenderUbo(RtContext* ctx, const RtUbo5* ubo, uint32_t mode, void* dst, size_t dst_pitch,
+                int dst_is_device, void* stream);
+
+/* Waits for the context's outstanding work and fills stats of the last render. */
+int rtGetStats(RtContext* ctx, RtStats* out);
+int rtSynchronize(RtContext* ctx);
+
+/* Arithmetic conformance probe (diagnostic): evaluates one operation per
+ * element on the GPU over host arrays — op 0 fma(a,b,c), 1 a/b, 2 sqrt(a),
+ * 3 a*b, 4 a+b, 5 RNG draw — so a CPU/GPU rounding difference can be pinned to
+ * a single operation.  No reference counterpart. */
+int rtSelfTestArith(RtContext* ctx, uint32_t op, const float* a, const float* b, const float* c,
+                    float* out, uint32_t n);
+
+/* ---- host-side helpers (no GPU needed) ---------------------------------- */
+
+/* RTCHAP06/main.cpp:101-120: width/height -> the UBO the reference fills
+ * (viewportWidth = 2, viewportHeight = 2/aspect, focalLength = 1). */
+int rtUboFromImage(uint32_t width, uint32_t height, RtUbo5* out);
+/* raytrace06.comp:53-56: origin 0, axis-aligned viewport, no lens. */
+int rtCameraFromUbo(const RtUbo5* ubo, RtCamera* out);
+/* SURVEY.md section 9.4 (book camera; vfov in degrees). */
+int rtMakeCamera(const float lookfrom[3], const float lookat[3], const float vup[3],
+                 float vfov_deg, float aspect, float aperture, float focus_dist, RtCamera* out);
+
+/* Scene builders.  `capacity` is the room in both arrays; *out_n the count made.
+ * rtMakeCoverScene: SURVEY.md section 9.6 random_scene on a (2*grid_half)^2 grid
+ * (grid_half = 11 -> ~485 spheres, 32 -> ~4000) drawn from the shared counter RNG. */
+int rtMakeCoverScene(uint32_t seed, int grid_half, RtSphere* spheres, RtMaterial* materials,
+                     uint32_t capacity, uint32_t* out_n);
+/* BASELINE config 2: ground + lambertian centre + dielectric left (+ optional
+ * inner r=-0.4 bubble) + metal right. */
+int rtMakeThreeSphereScene(int with_bubble, RtSphere* spheres, RtMaterial* materials,
+                           uint32_t capacity, uint32_t* out_n);
+
+/* Row tiling helpers (which rows a rank renders). */
+uint32_t rtTileRowCount(uint32_t height, uint32_t row_block, uint32_t tile_rank,
+                        uint32_t tile_count);
+/* global row of local row `local_row` of this tile */
+uint32_t rtTileGlobalRow(uint32_t local_row, uint32_t row_block, uint32_t tile_rank,
+                         uint32_t tile_count);
+
+/* Lossless writer replacing saveScreenCap (RTCHAP06/Vulkan.cpp:625-766): binary
+ * PPM "P6", top scene row first, i.e. buffer row H-1 first (rt.frag:8's flip). */
+int rtWritePPM(const char* path, const void* rgba8, uint32_t width, uint32_t height,
+               size_t pitch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTIOW_H */

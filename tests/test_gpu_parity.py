@@ -1,0 +1,200 @@
+"""GPU (-m gpu): the HIP path through the C ABI against the CPU oracle, bit for bit."""
+import ctypes as C
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import vulkan_rtiow_amd as V
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KERNELS = [V.KERNEL_PIXEL, V.KERNEL_PERSISTENT]
+
+
+def _diff(a, b):
+    d = np.abs(a.astype(int) - b.astype(int))
+    return int(d.max()), int((d > 0).sum())
+
+
+# ---- arithmetic contract -------------------------------------------------------
+@pytest.mark.parametrize("op,name", [(0, "fma"), (1, "div"), (2, "sqrt"), (3, "mul"), (4, "add"), (5, "rng")])
+def test_arith_bit_exact(gpu_ctx, oracle, op, name):
+    """fma / divide / sqrt / RNG on gfx950 == x86, including denormals, zeros and huge values."""
+    rng = np.random.default_rng(op)
+    n = 1 << 16
+    bits = rng.integers(0, 2**32, (3, n), dtype=np.uint64).astype(np.uint32)
+    a, b, c = (x.view(np.float32).copy() for x in bits)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 1e-45, -1e-45, 1.1754942e-38, 3.4e38, 1e-20, 0.001,
+                        0.999, 255.0, 1e6, 2.0 ** -126, 2.0 ** -149, 4.0, 0.25], np.float32)
+    k = len(special)
+    a[:k * k] = np.repeat(special, k)
+    b[:k * k] = np.tile(special, k)
+    c[:k] = special
+    if op == 2:
+        a = np.abs(a)
+    for arr in (a, b, c):  # NaN/inf payloads are outside the contract
+        arr[~np.isfinite(arr)] = 1.5
+    got = gpu_ctx.selftest_arith(op, a, b, c)
+    want = oracle.arith(op, a, b, c)
+    ok = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert ok.all(), (name, int((~ok).sum()), a[~ok][:4], b[~ok][:4], got[~ok][:4], want[~ok][:4])
+
+
+# ---- the reference's own kernels -------------------------------------------------
+@pytest.mark.parametrize("mode", [V.RT_MODE_CH05, V.RT_MODE_CH06])
+@pytest.mark.parametrize("w,h", [(800, 608), (400, 225), (1024, 1024), (33, 17), (16, 16), (1, 1), (1200, 800)])
+def test_ch_kernels_bit_exact(gpu_ctx, oracle, mode, w, h):
+    """raytrace05.comp / raytrace06.comp incl. ragged sizes the reference's floor-div/over-dispatch
+    would have mishandled (RTCHAP05 main.cpp:306, RTCHAP06 main.cpp:321)."""
+    ubo = oracle.ubo_from_image(w, h)
+    want = oracle.render_ubo(ubo, mode)
+    got = gpu_ctx.render_ubo(ubo, mode)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), _diff(got, want)
+    st = gpu_ctx.stats()
+    assert st.bytes_written == want.shape[0] * want.shape[1] * 4 and st.kernel_ms > 0
+
+
+def test_ch_known_answers_on_gpu(gpu_ctx):
+    """SURVEY 8(c) table straight against the HIP kernel (no oracle in the loop)."""
+    for row in json.load(open(os.path.join(GOLD, "ch_known_answers.json"))):
+        w, h = row["width"], row["height"]
+        ubo = V.ubo_from_image(w, h)
+        img5 = gpu_ctx.render_ubo(ubo, V.RT_MODE_CH05)
+        hit = (img5[..., 0] == 255) & (img5[..., 1] == 0)
+        ys, xs = np.nonzero(hit)
+        assert int(hit.sum()) == row["hit_px"]
+        assert [int(xs.min()), int(xs.max())] == row["bbox_x"] and [int(ys.min()), int(ys.max())] == row["bbox_y"]
+        img = img5 if row["mode"] == "CH05" else gpu_ctx.render_ubo(ubo, V.RT_MODE_CH06)
+        assert img[..., 3].max() == 0
+        for key, (y, x) in {"px00": (0, 0), "pxWH": (h - 1, w - 1), "centre": (h // 2, w // 2)}.items():
+            assert np.abs(img[y, x, :3].astype(int) - np.array(row[key])).max() <= 1
+
+
+def test_ch_via_rtrender_and_custom_ubo(gpu_ctx, oracle):
+    prm = V.make_params(400, 225, mode=V.RT_MODE_CH06)
+    got = gpu_ctx.render(None, prm)
+    assert np.array_equal(got, oracle.render_ubo(oracle.ubo_from_image(400, 225), V.RT_MODE_CH06))
+    ubo = V.RtUbo5(321.0, 123.0, 3.5, 2.0, 0.7)  # the book's "viewport height = 2" style values
+    assert np.array_equal(gpu_ctx.render_ubo(ubo, V.RT_MODE_CH06), oracle.render_ubo(ubo, V.RT_MODE_CH06))
+
+
+# ---- PATH mode -------------------------------------------------------------------
+def _case(oracle, scene, w, h):
+    from golden.make_golden import build_case
+    return build_case(V, oracle, scene, w, h)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_path_golden_crcs_on_gpu(gpu_ctx, oracle, kernel):
+    """Committed oracle CRCs (tests/golden/path_oracle_crc.json) reproduced by the HIP path."""
+    gold = json.load(open(os.path.join(GOLD, "path_oracle_crc.json")))
+    for name, g in gold.items():
+        sph, mat, cam = _case(oracle, g["scene"], g["width"], g["height"])
+        gpu_ctx.set_scene(sph, mat)
+        prm = V.make_params(g["width"], g["height"], spp=g["spp"], max_depth=g["max_depth"], seed=g["seed"],
+                            chunk_spp=g["chunk_spp"], quantiser=g["quantiser"], kernel=kernel)
+        img = gpu_ctx.render(cam, prm)
+        st = gpu_ctx.stats()
+        assert zlib.crc32(img.tobytes()) == g["frame_crc32"], name
+        assert st.segments == g["segments"], name
+        assert st.paths == g["width"] * g["height"] * g["spp"]
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("scene,w,h,spp,depth,chunk,quant", [
+    ("three", 400, 225, 8, 50, 0, V.RT_QUANT_BOOK),          # BASELINE config 2 shape, fewer spp
+    ("three_bubble", 131, 77, 6, 50, 4, V.RT_QUANT_UNORM8),  # negative radius + ragged chunks
+    ("cover11", 150, 100, 4, 50, 0, V.RT_QUANT_BOOK),        # BASELINE config 3 scene
+    ("cover11", 96, 64, 9, 5, 2, V.RT_QUANT_BOOK),           # depth exhaustion (black paths)
+    ("cover32", 64, 40, 2, 50, 1, V.RT_QUANT_BOOK),          # ~4000 spheres: BASELINE config 5 scene
+    ("cover3", 17, 9, 3, 50, 0, V.RT_QUANT_BOOK),            # image smaller than one tile
+])
+def test_path_bit_exact_vs_oracle(gpu_ctx, oracle, kernel, scene, w, h, spp, depth, chunk, quant):
+    sph, mat, cam = _case(oracle, scene, w, h)
+    gpu_ctx.set_scene(sph, mat)
+    prm = V.make_params(w, h, spp=spp, max_depth=depth, seed=11, chunk_spp=chunk, quantiser=quant, kernel=kernel)
+    want, segs = oracle.render(sph, mat, cam, prm)
+    got = gpu_ctx.render(cam, prm)
+    assert np.array_equal(got, want), _diff(got, want)   # stronger than the L_inf <= 1/255 bar
+    st = gpu_ctx.stats()
+    assert st.segments == segs and st.sphere_tests == segs * len(sph)
+    assert got[..., 3].max() == 0
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_path_tiles_reassemble_to_the_single_gpu_frame(gpu_ctx, oracle, kernel):
+    """1/2/4/8-GPU frames are byte-identical by construction: RNG keyed by the global pixel."""
+    w, h = 120, 83
+    sph, mat, cam = _case(oracle, "cover11", w, h)
+    gpu_ctx.set_scene(sph, mat)
+    base = V.make_params(w, h, spp=3, max_depth=20, seed=2, kernel=kernel)
+    full = gpu_ctx.render(cam, base)
+    for count, block in ((2, 16), (4, 8), (8, 4), (3, 1)):
+        frame = np.zeros_like(full)
+        for rank in range(count):
+            prm = V.make_params(w, h, spp=3, max_depth=20, seed=2, row_block=block, tile_rank=rank,
+                                tile_count=count, kernel=kernel)
+            part = gpu_ctx.render(cam, prm)
+            assert part.shape[0] == V.tile_row_count(h, block, rank, count)
+            for lr in range(part.shape[0]):
+                frame[V.tile_global_row(lr, block, rank, count)] = part[lr]
+        assert np.array_equal(frame, full), (count, block)
+
+
+def test_path_seed_and_determinism(gpu_ctx, oracle):
+    sph, mat, cam = _case(oracle, "three", 64, 36)
+    gpu_ctx.set_scene(sph, mat)
+    a = gpu_ctx.render(cam, V.make_params(64, 36, spp=4, seed=1))
+    b = gpu_ctx.render(cam, V.make_params(64, 36, spp=4, seed=1))
+    c = gpu_ctx.render(cam, V.make_params(64, 36, spp=4, seed=2))
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+def test_device_destination_and_pitch(gpu_ctx, oracle):
+    torch = pytest.importorskip("torch")
+    w, h = 50, 20
+    sph, mat, cam = _case(oracle, "three", w, h)
+    gpu_ctx.set_scene(sph, mat)
+    prm = V.make_params(w, h, spp=2, seed=3)
+    want = gpu_ctx.render(cam, prm)
+    pitch_px = 64
+    buf = torch.full((h, pitch_px), 0x7F7F7F7F, dtype=torch.int32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    gpu_ctx.render_device(cam, prm, buf.data_ptr(), pitch_px * 4, stream)
+    torch.cuda.synchronize()
+    host = buf.cpu().numpy().view(np.uint8).reshape(h, pitch_px, 4)
+    assert np.array_equal(host[:, :w], want)
+    assert (host[:, w:] == 0x7F).all()   # padding untouched
+
+
+def test_error_behaviour(gpu_ctx, oracle):
+    lib = V.load_library()
+    fresh = V.Context(0)
+    cam = V.camera_from_ubo(V.ubo_from_image(8, 8))
+    with pytest.raises(V.RtError) as e:
+        fresh.render(cam, V.make_params(8, 8, spp=1))      # PATH before rtSetScene
+    assert e.value.code == V.RT_ERR_STATE
+    sph, mat = V.make_three_sphere_scene()
+    fresh.set_scene(sph, mat)
+    for bad in (V.make_params(8, 8, spp=0), V.make_params(1, 8), V.make_params(8, 8, mode=99),
+                V.make_params(8, 8, quantiser=7), V.make_params(8, 8, tile_rank=2, tile_count=2)):
+        with pytest.raises(V.RtError) as e:
+            fresh.render(cam, bad)
+        assert e.value.code == V.RT_ERR_INVALID
+    bad_mat = mat.copy()
+    bad_mat["kind"][0] = 9
+    with pytest.raises(V.RtError):
+        fresh.set_scene(sph, bad_mat)
+    with pytest.raises(V.RtError):
+        fresh.set_scene(sph[:0], mat[:0])
+    out = np.zeros((8, 8, 4), np.uint8)
+    assert lib.rtRender(fresh._h, C.byref(cam), C.byref(V.make_params(8, 8)), out.ctypes.data, 30, 0, None) == V.RT_ERR_INVALID
+    assert b"pitch" in lib.rtGetLastError(fresh._h)
+    with pytest.raises(V.RtError) as e:
+        V.Context(99)
+    assert e.value.code == V.RT_ERR_NO_DEVICE
+    fresh.close()

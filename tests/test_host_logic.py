@@ -1,0 +1,105 @@
+"""CPU: the product's host side (scene builders, camera, tiling, writer, ABI surface)
+against the oracle's independent restatement.  No compute entry point is called."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import vulkan_rtiow_amd as V
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "rtiow.h")).read()
+    declared = set(re.findall(r"\b(rt[A-Z]\w+)\s*\(", header))
+    assert declared == set(V.api.SIGNATURES), declared ^ set(V.api.SIGNATURES)
+    lib = V.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.rtAbiVersion() == 1
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(V.RtUbo5) == 20          # raytrace06.comp:4-10 / main.cpp:109-115
+    assert C.sizeof(V.RtSphere) == 16
+    assert C.sizeof(V.RtMaterial) == 32
+    assert C.sizeof(V.RtCamera) == 88
+    assert C.sizeof(V.RtParams) == 48
+
+
+def test_ubo_formula_matches_reference_main_cpp(oracle):
+    for w, h in ((800, 608), (400, 225), (1200, 800), (1, 1), (3840, 2160)):
+        a, b = V.ubo_from_image(w, h), oracle.ubo_from_image(w, h)
+        assert bytes(a) == bytes(b)
+    u = V.ubo_from_image(800, 608)
+    assert (u.imageWidth, u.imageHeight, u.viewportWidth, u.focalLength) == (800.0, 608.0, 2.0, 1.0)
+    assert u.viewportHeight == np.float32(2.0) / (np.float32(800) / np.float32(608))
+
+
+def test_cameras_match_oracle(oracle):
+    ubo = V.ubo_from_image(400, 225)
+    assert bytes(V.camera_from_ubo(ubo)) == bytes(oracle.camera_from_ubo(ubo))
+    args = ((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, 1.5, 0.1, 10.0)
+    assert bytes(V.make_camera(*args)) == bytes(oracle.make_camera(*args))
+    args = ((-2, 2, 1), (0, 0, -1), (0, 1, 0), 90.0, 16 / 9, 0.0, 1.0)
+    assert bytes(V.make_camera(*args)) == bytes(oracle.make_camera(*args))
+
+
+@pytest.mark.parametrize("seed,half", [(1, 11), (2, 11), (1, 3), (9, 32), (1, 0)])
+def test_cover_scene_matches_oracle(oracle, seed, half):
+    s1, m1 = V.make_cover_scene(seed, half)
+    s2, m2 = oracle.make_cover_scene(seed, half)
+    assert s1.tobytes() == s2.tobytes() and m1.tobytes() == m2.tobytes()
+    assert len(s1) <= (2 * half) ** 2 + 4
+
+
+def test_cover_scene_shape():
+    sph, mat = V.make_cover_scene(1, 11)
+    assert 470 <= len(sph) <= 488            # "~485 spheres"
+    assert sph[0]["radius"] == 1000.0 and mat[0]["kind"] == V.RT_MAT_LAMBERTIAN
+    kinds = np.bincount(mat["kind"][1:-3], minlength=3) / (len(sph) - 4)
+    assert 0.7 < kinds[0] < 0.9 and 0.08 < kinds[1] < 0.22 and 0.01 < kinds[2] < 0.1
+    big, _ = V.make_cover_scene(1, 32)
+    assert 4000 <= len(big) <= 4100          # BASELINE config 5
+
+
+def test_three_sphere_scene_matches_oracle(oracle):
+    for bubble in (False, True):
+        s1, m1 = V.make_three_sphere_scene(bubble)
+        s2, m2 = oracle.make_three_sphere_scene(bubble)
+        assert s1.tobytes() == s2.tobytes() and m1.tobytes() == m2.tobytes()
+        assert len(s1) == 4 + int(bubble)
+
+
+def test_tile_rows_partition_the_image(oracle):
+    for h, block, count in ((800, 16, 8), (803, 16, 8), (225, 4, 2), (7, 3, 4), (2160, 8, 8), (5, 1, 1), (9, 0, 3)):
+        seen = []
+        for rank in range(count):
+            n = V.tile_row_count(h, block, rank, count)
+            assert n == oracle.lib.oracle_tile_row_count(h, block, rank, count)
+            rows = [V.tile_global_row(lr, block, rank, count) for lr in range(n)]
+            assert rows == [oracle.lib.oracle_tile_global_row(lr, block, rank, count) for lr in range(n)]
+            assert rows == sorted(rows)
+            seen += rows
+        assert sorted(seen) == list(range(h))
+
+
+def test_ppm_writer_matches_oracle(oracle, tmp_path):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (13, 7, 4), dtype=np.uint8)
+    V.write_ppm(str(tmp_path / "a.ppm"), img)
+    oracle.write_ppm(str(tmp_path / "b.ppm"), img)
+    a, b = (tmp_path / "a.ppm").read_bytes(), (tmp_path / "b.ppm").read_bytes()
+    assert a == b and a.startswith(b"P6\n7 13\n255\n")
+
+
+def test_error_codes_without_gpu_or_context():
+    lib = V.load_library()
+    assert lib.rtRender(None, None, None, None, 0, 0, None) == V.RT_ERR_INVALID
+    assert lib.rtSetScene(None, None, None, 0) == V.RT_ERR_INVALID
+    assert lib.rtUboFromImage(0, 5, C.byref(V.RtUbo5())) == V.RT_ERR_INVALID
+    assert lib.rtWritePPM(b"/nonexistent-dir/x.ppm", np.zeros(16, np.uint8).ctypes.data, 2, 2, 8) == V.RT_ERR_IO
+    assert lib.rtDestroy(None) == V.RT_OK

@@ -1,0 +1,128 @@
+"""CPU: pins the oracle against the reference's own result fixtures and the committed
+golden vectors (no GPU, no /root/reference access at run time)."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import vulkan_rtiow_amd as V
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _hits(oracle, w, h):
+    img = oracle.render_ubo(oracle.ubo_from_image(w, h), V.RT_MODE_CH05)
+    return (img[..., 0] == 255) & (img[..., 1] == 0) & (img[..., 2] == 0)
+
+
+@pytest.mark.parametrize("row", json.load(open(os.path.join(GOLD, "ch_known_answers.json"))),
+                         ids=lambda r: f"{r['mode']}_{r['width']}x{r['height']}")
+def test_ch_known_answers(oracle, row):
+    """raytrace05.comp / raytrace06.comp at the reference's UBO formula."""
+    w, h = row["width"], row["height"]
+    mode = V.RT_MODE_CH05 if row["mode"] == "CH05" else V.RT_MODE_CH06
+    ubo = oracle.ubo_from_image(w, h)
+    img = oracle.render_ubo(ubo, mode)
+    assert img.shape == (h, w, 4)
+    assert img[..., 3].max() == 0  # imageStore(vec4(color,0.0)): raytrace06.comp:66
+    hit = _hits(oracle, w, h)
+    ys, xs = np.nonzero(hit)
+    assert int(hit.sum()) == row["hit_px"]
+    assert [int(xs.min()), int(xs.max())] == row["bbox_x"]
+    assert [int(ys.min()), int(ys.max())] == row["bbox_y"]
+    # colours: the table is robust to +-1 LSB (FMA contraction is the driver's choice)
+    probes = {"px00": (0, 0), "pxWH": (h - 1, w - 1), "centre": (h // 2, w // 2),
+              "mid_ymin5": (int(ys.min()) + 5, w // 2), "xmin5_mid": (h // 2, int(xs.min()) + 5)}
+    for key, (y, x) in probes.items():
+        got = img[y, x, :3].astype(int)
+        assert np.abs(got - np.array(row[key])).max() <= 1, (key, got, row[key])
+
+
+def test_ch05_against_reference_jpeg(oracle):
+    """The only result fixture the reference holds: RTCHAP05/RTCHAP05/21986.jpg (800x608,
+    display orientation = buffer flipped in y by rt.frag:8)."""
+    st = json.load(open(os.path.join(GOLD, "ref_jpeg_stats.json")))["RTCHAP05/RTCHAP05/21986.jpg"]
+    w, h = st["size"]
+    img = oracle.render_ubo(oracle.ubo_from_image(w, h), V.RT_MODE_CH05)[::-1]  # to display rows
+    hit = (img[..., 0] == 255) & (img[..., 1] == 0)
+    ys, xs = np.nonzero(hit)
+    assert int(hit.sum()) == st["red_count"]
+    assert [int(xs.min()), int(xs.max())] == st["red_bbox_x"]
+    assert [int(ys.min()), int(ys.max())] == st["red_bbox_y"]
+    tol = st["jpeg_tolerance"]
+    for key, (y, x) in {"top_left": (0, 0), "bottom_left": (h - 1, 0), "top_right": (0, w - 1),
+                        "bottom_right": (h - 1, w - 1)}.items():
+        assert np.abs(img[y, x, :3].astype(int) - np.array(st[key])).max() <= tol, key
+
+
+def test_gradient_against_rt01_jpeg(oracle):
+    """RT01/RT01/4068.jpg pins the sky gradient's end colours (800x600 window over a 1024^2
+    image with viewport 2x2: top/bottom middle of the picture see unit.y = +-1/sqrt(2))."""
+    st = json.load(open(os.path.join(GOLD, "ref_jpeg_stats.json")))["RT01/RT01/4068.jpg"]
+    ubo = V.RtUbo5(1024.0, 1024.0, 2.0, 2.0, 1.0)
+    # RT01's sphere-free kernel == the miss branch; CH06 differs only inside the sphere
+    img = oracle.render_ubo(ubo, V.RT_MODE_CH06)[::-1]
+    tol = st["jpeg_tolerance"]
+    assert np.abs(img[0, 512, :3].astype(int) - np.array(st["top_mid"])).max() <= tol
+    assert np.abs(img[1023, 512, :3].astype(int) - np.array(st["bottom_mid"])).max() <= tol
+
+
+def test_path_regression_crcs(oracle):
+    """PATH frames of the oracle itself (parity unpinned by the reference): guards the spec."""
+    from golden.make_golden import build_case
+    gold = json.load(open(os.path.join(GOLD, "path_oracle_crc.json")))
+    for name, g in gold.items():
+        sph, mat, cam = build_case(V, oracle, g["scene"], g["width"], g["height"])
+        assert len(sph) == g["n_spheres"]
+        assert zlib.crc32(sph.tobytes() + mat.tobytes()) == g["scene_crc32"], name
+        prm = V.make_params(g["width"], g["height"], spp=g["spp"], max_depth=g["max_depth"],
+                            seed=g["seed"], chunk_spp=g["chunk_spp"], quantiser=g["quantiser"])
+        img, segs = oracle.render(sph, mat, cam, prm, nthreads=4)
+        assert segs == g["segments"], name
+        assert zlib.crc32(img.tobytes()) == g["frame_crc32"], name
+
+
+def test_path_thread_count_and_tiles_do_not_change_pixels(oracle):
+    sph, mat = oracle.make_three_sphere_scene(True)
+    w, h = 37, 23
+    cam = oracle.camera_from_ubo(oracle.ubo_from_image(w, h))
+    prm = V.make_params(w, h, spp=3, max_depth=10, seed=5)
+    full, segs = oracle.render(sph, mat, cam, prm, nthreads=1)
+    full8, segs8 = oracle.render(sph, mat, cam, prm, nthreads=8)
+    assert np.array_equal(full, full8) and segs == segs8
+    # block-cyclic row tiles reassemble to the same frame (RNG keyed by global pixel)
+    for count, block in ((2, 4), (3, 1), (8, 2)):
+        frame = np.zeros_like(full)
+        total = 0
+        for rank in range(count):
+            p = V.make_params(w, h, spp=3, max_depth=10, seed=5, row_block=block, tile_rank=rank,
+                              tile_count=count)
+            part, s = oracle.render(sph, mat, cam, p)
+            total += s
+            for lr in range(part.shape[0]):
+                frame[oracle.lib.oracle_tile_global_row(lr, block, rank, count)] = part[lr]
+        assert np.array_equal(frame, full) and total == segs
+
+
+def test_path_degenerates_to_reference_camera(oracle):
+    """With aperture 0, origin 0 the thin-lens camera is raytrace06.comp:53-61's ray generation."""
+    ubo = oracle.ubo_from_image(64, 48)
+    cam = oracle.camera_from_ubo(ubo)
+    assert cam.lens_radius == 0.0
+    assert list(cam.lower_left) == [-1.0, -ubo.viewportHeight / 2, -1.0]
+    assert list(cam.horizontal) == [2.0, 0.0, 0.0]
+    assert list(cam.vertical) == [0.0, ubo.viewportHeight, 0.0]
+
+
+def test_ppm_is_flipped_like_rt_frag(oracle, tmp_path):
+    img = np.zeros((3, 2, 4), np.uint8)
+    img[0, :, 0] = 10   # buffer row 0 = scene bottom
+    img[2, :, 0] = 30
+    p = tmp_path / "o.ppm"
+    oracle.write_ppm(str(p), img)
+    data = p.read_bytes()
+    assert data.startswith(b"P6\n2 3\n255\n")
+    body = np.frombuffer(data[len(b"P6\n2 3\n255\n"):], np.uint8).reshape(3, 2, 3)
+    assert body[0, 0, 0] == 30 and body[2, 0, 0] == 10

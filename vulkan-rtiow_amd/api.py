@@ -1,0 +1,271 @@
+"""ctypes binding of the C ABI declared in include/rtiow.h.
+
+This is the Python host side of the drop-in boundary: it mirrors the reference's
+resource/dispatch interface (camera UBO in, RGBA8 image out —
+RTCHAP06/main.cpp:109-157 and :313-325) one call for one call.  There is no
+CPU fallback here: if librtiow_hip.so is missing, or no GPU is usable, the
+calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtiow_hip.so")
+
+# ---- enums (include/rtiow.h) -------------------------------------------------
+RT_OK = 0
+RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_NOMEM, RT_ERR_STATE, RT_ERR_IO = 1, 2, 3, 4, 5, 6
+RT_MODE_CH05, RT_MODE_CH06, RT_MODE_PATH = 5, 6, 13
+RT_QUANT_UNORM8, RT_QUANT_BOOK = 0, 1
+RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_DIELECTRIC = 0, 1, 2
+KERNEL_DEFAULT, KERNEL_PIXEL, KERNEL_PERSISTENT = 0, 1, 2
+
+
+class RtUbo5(C.Structure):
+    _fields_ = [(n, C.c_float) for n in
+                ("imageWidth", "imageHeight", "viewportWidth", "viewportHeight", "focalLength")]
+
+
+class RtSphere(C.Structure):
+    _fields_ = [("cx", C.c_float), ("cy", C.c_float), ("cz", C.c_float), ("radius", C.c_float)]
+
+
+class RtMaterial(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("albedo", C.c_float * 3), ("fuzz", C.c_float),
+                ("ior", C.c_float), ("pad", C.c_uint32 * 2)]
+
+
+class RtCamera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("lower_left", C.c_float * 3),
+                ("horizontal", C.c_float * 3), ("vertical", C.c_float * 3),
+                ("u", C.c_float * 3), ("v", C.c_float * 3), ("w", C.c_float * 3),
+                ("lens_radius", C.c_float)]
+
+
+class RtParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in
+                ("width", "height", "spp", "max_depth", "seed", "mode", "quantiser", "chunk_spp",
+                 "row_block", "tile_rank", "tile_count", "kernel")]
+
+
+class RtStats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("paths", C.c_uint64), ("segments", C.c_uint64),
+                ("sphere_tests", C.c_uint64), ("bytes_written", C.c_uint64),
+                ("rows_rendered", C.c_uint32), ("n_spheres", C.c_uint32)]
+
+
+SPHERE_DTYPE = np.dtype([("cx", "<f4"), ("cy", "<f4"), ("cz", "<f4"), ("radius", "<f4")])
+MATERIAL_DTYPE = np.dtype([("kind", "<u4"), ("albedo", "<f4", (3,)), ("fuzz", "<f4"),
+                           ("ior", "<f4"), ("pad", "<u4", (2,))])
+assert SPHERE_DTYPE.itemsize == 16 and MATERIAL_DTYPE.itemsize == 32
+assert C.sizeof(RtUbo5) == 20 and C.sizeof(RtMaterial) == 32 and C.sizeof(RtCamera) == 88
+
+# every symbol include/rtiow.h declares, with its signature
+_VP = C.c_void_p
+SIGNATURES = {
+    "rtCreate": (C.c_int, [C.c_int, C.POINTER(_VP)]),
+    "rtDestroy": (C.c_int, [_VP]),
+    "rtGetLastError": (C.c_char_p, [_VP]),
+    "rtAbiVersion": (C.c_int, []),
+    "rtSetScene": (C.c_int, [_VP, _VP, _VP, C.c_uint32]),
+    "rtRender": (C.c_int, [_VP, C.POINTER(RtCamera), C.POINTER(RtParams), _VP, C.c_size_t, C.c_int, _VP]),
+    "rtRenderUbo": (C.c_int, [_VP, C.POINTER(RtUbo5), C.c_uint32, _VP, C.c_size_t, C.c_int, _VP]),
+    "rtGetStats": (C.c_int, [_VP, C.POINTER(RtStats)]),
+    "rtSynchronize": (C.c_int, [_VP]),
+    "rtSelfTestArith": (C.c_int, [_VP, C.c_uint32, _VP, _VP, _VP, _VP, C.c_uint32]),
+    "rtUboFromImage": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(RtUbo5)]),
+    "rtCameraFromUbo": (C.c_int, [C.POINTER(RtUbo5), C.POINTER(RtCamera)]),
+    "rtMakeCamera": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                               C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(RtCamera)]),
+    "rtMakeCoverScene": (C.c_int, [C.c_uint32, C.c_int, _VP, _VP, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "rtMakeThreeSphereScene": (C.c_int, [C.c_int, _VP, _VP, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "rtTileRowCount": (C.c_uint32, [C.c_uint32] * 4),
+    "rtTileGlobalRow": (C.c_uint32, [C.c_uint32] * 4),
+    "rtWritePPM": (C.c_int, [C.c_char_p, _VP, C.c_uint32, C.c_uint32, C.c_size_t]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class RtError(RuntimeError):
+    def __init__(self, code: int, where: str, detail: str = ""):
+        super().__init__(f"{where} failed with status {code}" + (f": {detail}" if detail else ""))
+        self.code = code
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """Loads librtiow_hip.so and types every exported entry point.  Raises if it is absent."""
+    global _lib
+    if _lib is not None and path == LIB_PATH:
+        return _lib
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the render path.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.rtAbiVersion() != 1:
+        raise ImportError("librtiow_hip.so has an unexpected ABI version")
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+def _f3(v: Sequence[float]):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+# ---- host-side helpers (no GPU) ------------------------------------------------
+def ubo_from_image(width: int, height: int) -> RtUbo5:
+    ubo = RtUbo5()
+    _check(None, load_library().rtUboFromImage(width, height, C.byref(ubo)), "rtUboFromImage")
+    return ubo
+
+
+def camera_from_ubo(ubo: RtUbo5) -> RtCamera:
+    cam = RtCamera()
+    _check(None, load_library().rtCameraFromUbo(C.byref(ubo), C.byref(cam)), "rtCameraFromUbo")
+    return cam
+
+
+def make_camera(lookfrom, lookat, vup, vfov_deg, aspect, aperture, focus_dist) -> RtCamera:
+    cam = RtCamera()
+    _check(None, load_library().rtMakeCamera(_f3(lookfrom), _f3(lookat), _f3(vup), vfov_deg, aspect,
+                                             aperture, focus_dist, C.byref(cam)), "rtMakeCamera")
+    return cam
+
+
+def make_cover_scene(seed: int = 1, grid_half: int = 11) -> Tuple[np.ndarray, np.ndarray]:
+    cap = (2 * grid_half) ** 2 + 8
+    sph = np.zeros(cap, SPHERE_DTYPE)
+    mat = np.zeros(cap, MATERIAL_DTYPE)
+    n = C.c_uint32(0)
+    _check(None, load_library().rtMakeCoverScene(seed, grid_half, sph.ctypes.data, mat.ctypes.data,
+                                                 cap, C.byref(n)), "rtMakeCoverScene")
+    return sph[:n.value].copy(), mat[:n.value].copy()
+
+
+def make_three_sphere_scene(with_bubble: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    sph = np.zeros(8, SPHERE_DTYPE)
+    mat = np.zeros(8, MATERIAL_DTYPE)
+    n = C.c_uint32(0)
+    _check(None, load_library().rtMakeThreeSphereScene(int(with_bubble), sph.ctypes.data,
+                                                       mat.ctypes.data, 8, C.byref(n)),
+           "rtMakeThreeSphereScene")
+    return sph[:n.value].copy(), mat[:n.value].copy()
+
+
+def tile_row_count(height: int, row_block: int, rank: int, count: int) -> int:
+    return int(load_library().rtTileRowCount(height, row_block, rank, count))
+
+
+def tile_global_row(local_row: int, row_block: int, rank: int, count: int) -> int:
+    return int(load_library().rtTileGlobalRow(local_row, row_block, rank, count))
+
+
+def write_ppm(path: str, rgba8: np.ndarray) -> None:
+    img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    h, w = img.shape[:2]
+    _check(None, load_library().rtWritePPM(os.fsencode(path), img.ctypes.data, w, h, w * 4), "rtWritePPM")
+
+
+def _check(ctx, code: int, where: str) -> None:
+    if code != RT_OK:
+        lib = load_library()
+        msg = lib.rtGetLastError(ctx)
+        raise RtError(code, where, msg.decode() if msg else "")
+
+
+def make_params(width, height, spp=1, max_depth=50, seed=1, mode=RT_MODE_PATH,
+                quantiser=RT_QUANT_BOOK, chunk_spp=0, row_block=0, tile_rank=0, tile_count=0,
+                kernel=KERNEL_DEFAULT) -> RtParams:
+    return RtParams(width, height, spp, max_depth, seed, mode, quantiser, chunk_spp, row_block,
+                    tile_rank, tile_count, kernel)
+
+
+class Context:
+    """One GPU's render context (rtCreate .. rtDestroy)."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = load_library()
+        self._h = _VP()
+        code = self._lib.rtCreate(device_id, C.byref(self._h))
+        if code != RT_OK:
+            msg = self._lib.rtGetLastError(None)
+            raise RtError(code, "rtCreate", msg.decode() if msg else "")
+        self.device_id = device_id
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.rtDestroy(self._h)
+            self._h = _VP()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_scene(self, spheres: np.ndarray, materials: np.ndarray) -> None:
+        sph = np.ascontiguousarray(spheres, dtype=SPHERE_DTYPE)
+        mat = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
+        if len(sph) != len(mat):
+            raise ValueError("spheres and materials differ in length")
+        _check(self._h, self._lib.rtSetScene(self._h, sph.ctypes.data, mat.ctypes.data, len(sph)),
+               "rtSetScene")
+
+    def render(self, cam: Optional[RtCamera], params: RtParams) -> np.ndarray:
+        """Renders this tile's rows into a host array [rows, width, 4] (row 0 = scene bottom)."""
+        rows = tile_row_count(params.height, params.row_block, params.tile_rank, params.tile_count)
+        out = np.zeros((rows, params.width, 4), np.uint8)
+        dst = out.ctypes.data if rows else np.zeros(4, np.uint8).ctypes.data
+        _check(self._h, self._lib.rtRender(self._h, C.byref(cam) if cam is not None else None,
+                                           C.byref(params), dst, params.width * 4, 0, None),
+               "rtRender")
+        return out
+
+    def render_device(self, cam: Optional[RtCamera], params: RtParams, dst_ptr: int, pitch: int,
+                      stream: int = 0) -> None:
+        """Enqueues the render into device memory `dst_ptr` on hipStream_t `stream` (no host sync)."""
+        _check(self._h, self._lib.rtRender(self._h, C.byref(cam) if cam is not None else None,
+                                           C.byref(params), _VP(dst_ptr), pitch, 1,
+                                           _VP(stream) if stream else None), "rtRender")
+
+    def render_ubo(self, ubo: RtUbo5, mode: int) -> np.ndarray:
+        w, h = int(ubo.imageWidth), int(ubo.imageHeight)
+        out = np.zeros((h, w, 4), np.uint8)
+        _check(self._h, self._lib.rtRenderUbo(self._h, C.byref(ubo), mode, out.ctypes.data, w * 4, 0,
+                                              None), "rtRenderUbo")
+        return out
+
+    def synchronize(self) -> None:
+        _check(self._h, self._lib.rtSynchronize(self._h), "rtSynchronize")
+
+    def stats(self) -> RtStats:
+        st = RtStats()
+        _check(self._h, self._lib.rtGetStats(self._h, C.byref(st)), "rtGetStats")
+        return st
+
+    def selftest_arith(self, op: int, a: np.ndarray, b: np.ndarray, c: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        c = np.ascontiguousarray(c, np.float32)
+        out = np.zeros_like(a)
+        _check(self._h, self._lib.rtSelfTestArith(self._h, op, a.ctypes.data, b.ctypes.data,
+                                                  c.ctypes.data, out.ctypes.data, a.size),
+               "rtSelfTestArith")
+        return out

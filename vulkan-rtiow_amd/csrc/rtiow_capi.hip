@@ -1,0 +1,349 @@
+// rtiow_capi.hip — the thin C-ABI layer over the gfx950 kernels: context
+// lifetime, scene upload, the render dispatch and its statistics.  It stands
+// where RTCHAP06/main.cpp:100-157 (resource setup) and :313-325 (per-frame
+// compute submit) stand in the reference.  There is no CPU fallback: without a
+// usable GPU every device entry point fails with RT_ERR_NO_DEVICE / RT_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+
+#include "../../include/rtiow.h"
+#include "rtiow_device.h"
+
+struct RtContext {
+    int device = -1;
+    int num_cus = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    float4* d_spheres = nullptr;
+    RtMaterial* d_materials = nullptr;
+    uint32_t n_spheres = 0;
+    rtiow::Counters* d_counters = nullptr;
+    rtiow::Counters* h_counters = nullptr;  // pinned
+    uint32_t* d_frame = nullptr;            // staging framebuffer for host destinations
+    size_t frame_bytes = 0;
+    float4* d_partials = nullptr;
+    size_t partials_bytes = 0;
+    bool have_timing = false;
+    hipStream_t last_stream = nullptr;
+    RtStats stats{};
+    std::string error;
+};
+
+namespace {
+
+std::mutex g_err_mutex;
+std::string g_error;  // errors with no context to hang them on
+
+int fail(RtContext* ctx, int code, const std::string& msg) {
+    if (ctx) {
+        ctx->error = msg;
+    } else {
+        std::lock_guard<std::mutex> lock(g_err_mutex);
+        g_error = msg;
+    }
+    return code;
+}
+
+int fail_hip(RtContext* ctx, hipError_t e, const char* what) {
+    return fail(ctx, RT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define RT_HIP(ctx, call)                                   \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess) return fail_hip(ctx, e_, #call); \
+    } while (0)
+
+int ensure_bytes(RtContext* ctx, void** ptr, size_t* have, size_t need) {
+    if (*have >= need) return RT_OK;
+    if (*ptr) {
+        RT_HIP(ctx, hipFree(*ptr));
+        *ptr = nullptr;
+        *have = 0;
+    }
+    hipError_t e = hipMalloc(ptr, need);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    *have = need;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rtGetLastError(const RtContext* ctx) {
+    if (ctx) return ctx->error.c_str();
+    std::lock_guard<std::mutex> lock(g_err_mutex);
+    static thread_local std::string copy;
+    copy = g_error;
+    return copy.c_str();
+}
+
+int rtCreate(int device_id, RtContext** out_ctx) {
+    if (!out_ctx) return fail(nullptr, RT_ERR_INVALID, "rtCreate: out_ctx is null");
+    *out_ctx = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(nullptr, RT_ERR_NO_DEVICE,
+                    std::string("rtCreate: no HIP device (") + hipGetErrorString(e) + ")");
+    if (device_id < 0 || device_id >= count)
+        return fail(nullptr, RT_ERR_NO_DEVICE, "rtCreate: device_id out of range");
+    RtContext* ctx = new (std::nothrow) RtContext;
+    if (!ctx) return fail(nullptr, RT_ERR_NOMEM, "rtCreate: out of host memory");
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if ((e = hipSetDevice(device_id)) != hipSuccess ||
+        (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev_start)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev_stop)) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), sizeof(rtiow::Counters))) != hipSuccess ||
+        (e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counters), sizeof(rtiow::Counters))) != hipSuccess) {
+        int rc = fail_hip(nullptr, e, "rtCreate");
+        rtDestroy(ctx);
+        return rc;
+    }
+    ctx->num_cus = prop.multiProcessorCount;
+    std::memset(ctx->h_counters, 0, sizeof(rtiow::Counters));
+    *out_ctx = ctx;
+    return RT_OK;
+}
+
+int rtDestroy(RtContext* ctx) {
+    if (!ctx) return RT_OK;
+    if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_spheres) (void)hipFree(ctx->d_spheres);
+    if (ctx->d_materials) (void)hipFree(ctx->d_materials);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+    if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RT_OK;
+}
+
+int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materials,
+               uint32_t n_spheres) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rtSetScene: ctx is null");
+    if (!spheres || !materials || n_spheres == 0)
+        return fail(ctx, RT_ERR_INVALID, "rtSetScene: empty scene or null arrays");
+    // sphere list {cx,cy,cz,r*r} must fit the 160 KiB LDS of a gfx950 CU with room to spare
+    if (n_spheres > 8192) return fail(ctx, RT_ERR_INVALID, "rtSetScene: more than 8192 spheres");
+    for (uint32_t i = 0; i < n_spheres; ++i) {
+        if (materials[i].kind > RT_MAT_DIELECTRIC)
+            return fail(ctx, RT_ERR_INVALID, "rtSetScene: unknown material kind");
+        if (!(spheres[i].radius != 0.0f))
+            return fail(ctx, RT_ERR_INVALID, "rtSetScene: zero or NaN radius");
+    }
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_spheres) RT_HIP(ctx, hipFree(ctx->d_spheres));
+    if (ctx->d_materials) RT_HIP(ctx, hipFree(ctx->d_materials));
+    ctx->d_spheres = nullptr;
+    ctx->d_materials = nullptr;
+    ctx->n_spheres = 0;
+    RT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_spheres), sizeof(float4) * n_spheres));
+    RT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_materials), sizeof(RtMaterial) * n_spheres));
+    static_assert(sizeof(RtSphere) == sizeof(float4), "RtSphere must be 16 bytes");
+    static_assert(sizeof(RtMaterial) == 32, "RtMaterial must be 32 bytes");
+    // fuzz clamped to [0,1] as the book's metal constructor does
+    RtMaterial* tmp = new (std::nothrow) RtMaterial[n_spheres];
+    if (!tmp) return fail(ctx, RT_ERR_NOMEM, "rtSetScene: out of host memory");
+    for (uint32_t i = 0; i < n_spheres; ++i) {
+        tmp[i] = materials[i];
+        if (!(tmp[i].fuzz < 1.0f)) tmp[i].fuzz = 1.0f;
+        if (!(tmp[i].fuzz > 0.0f)) tmp[i].fuzz = 0.0f;
+    }
+    hipError_t e = hipMemcpy(ctx->d_materials, tmp, sizeof(RtMaterial) * n_spheres, hipMemcpyHostToDevice);
+    delete[] tmp;
+    if (e != hipSuccess) return fail_hip(ctx, e, "hipMemcpy(materials)");
+    RT_HIP(ctx, hipMemcpy(ctx->d_spheres, spheres, sizeof(float4) * n_spheres, hipMemcpyHostToDevice));
+    ctx->n_spheres = n_spheres;
+    return RT_OK;
+}
+
+static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const RtCamera* cam,
+                         const RtParams* prm, void* dst, size_t dst_pitch, int dst_is_device,
+                         void* stream_handle) {
+    const uint32_t W = prm->width, H = prm->height;
+    if (W == 0 || H == 0) return fail(ctx, RT_ERR_INVALID, "rtRender: empty image");
+    if (!dst) return fail(ctx, RT_ERR_INVALID, "rtRender: dst is null");
+    if (dst_pitch < size_t(W) * 4 || (dst_pitch & 3u))
+        return fail(ctx, RT_ERR_INVALID, "rtRender: dst_pitch must be >= 4*width and a multiple of 4");
+    uint32_t tcount = prm->tile_count <= 1 ? 1u : prm->tile_count;
+    uint32_t rblock = prm->row_block == 0 ? 1u : prm->row_block;
+    if (tcount > 1 && prm->tile_rank >= tcount)
+        return fail(ctx, RT_ERR_INVALID, "rtRender: tile_rank >= tile_count");
+    const uint32_t rows = rtTileRowCount(H, rblock, prm->tile_rank, tcount);
+
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = stream_handle ? static_cast<hipStream_t>(stream_handle) : ctx->stream;
+
+    uint32_t* out = static_cast<uint32_t*>(dst);
+    uint32_t out_stride = static_cast<uint32_t>(dst_pitch / 4);
+    if (!dst_is_device) {
+        int rc = ensure_bytes(ctx, reinterpret_cast<void**>(&ctx->d_frame), &ctx->frame_bytes,
+                              size_t(W) * 4 * (rows ? rows : 1));
+        if (rc != RT_OK) return rc;
+        out = ctx->d_frame;
+        out_stride = W;
+    }
+
+    ctx->stats = RtStats{};
+    ctx->stats.rows_rendered = rows;
+    ctx->stats.bytes_written = uint64_t(rows) * W * 4;
+    ctx->stats.n_spheres = is_ch ? 1u : ctx->n_spheres;
+    ctx->have_timing = false;
+    ctx->last_stream = stream;
+    if (rows == 0) return RT_OK;
+
+    RT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(rtiow::Counters), stream));
+    RT_HIP(ctx, hipEventRecord(ctx->ev_start, stream));
+    if (is_ch) {
+        rtiow::ChArgs a{};
+        a.ubo = *ubo;
+        a.mode = prm->mode;
+        a.width = W;
+        a.height = H;
+        a.dst = out;
+        a.dst_stride = out_stride;
+        RT_HIP(ctx, rtiow::launch_ch(a, stream));
+    } else {
+        rtiow::PathArgs a{};
+        a.spheres = ctx->d_spheres;
+        a.materials = ctx->d_materials;
+        a.n = ctx->n_spheres;
+        a.cam = *cam;
+        a.width = W;
+        a.height = H;
+        a.spp = prm->spp;
+        a.max_depth = prm->max_depth;
+        a.seed = prm->seed;
+        a.quantiser = prm->quantiser;
+        a.chunk_spp = (prm->chunk_spp == 0 || prm->chunk_spp > prm->spp) ? prm->spp : prm->chunk_spp;
+        a.row_block = rblock;
+        a.tile_rank = tcount > 1 ? prm->tile_rank : 0u;
+        a.tile_count = tcount;
+        a.local_rows = rows;
+        a.dst = out;
+        a.dst_stride = out_stride;
+        a.counters = ctx->d_counters;
+        const size_t need = rtiow::path_partials_bytes(a, prm->kernel);
+        if (need) {
+            int rc = ensure_bytes(ctx, reinterpret_cast<void**>(&ctx->d_partials),
+                                  &ctx->partials_bytes, need);
+            if (rc != RT_OK) return rc;
+        }
+        a.partials = ctx->d_partials;
+        RT_HIP(ctx, rtiow::launch_path(a, prm->kernel, ctx->num_cus, stream));
+    }
+    RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream));
+    RT_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(rtiow::Counters),
+                               hipMemcpyDeviceToHost, stream));
+    ctx->have_timing = true;
+
+    if (!dst_is_device) {
+        RT_HIP(ctx, hipMemcpy2DAsync(dst, dst_pitch, ctx->d_frame, size_t(W) * 4, size_t(W) * 4,
+                                     rows, hipMemcpyDeviceToHost, stream));
+        RT_HIP(ctx, hipStreamSynchronize(stream));
+    }
+    return RT_OK;
+}
+
+int rtRender(RtContext* ctx, const RtCamera* cam, const RtParams* params, void* dst,
+             size_t dst_pitch, int dst_is_device, void* stream) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rtRender: ctx is null");
+    if (!params) return fail(ctx, RT_ERR_INVALID, "rtRender: params is null");
+    if (params->mode == RT_MODE_CH05 || params->mode == RT_MODE_CH06) {
+        // the reference's own kernels take their camera from the 5-float UBO
+        RtUbo5 ubo;
+        if (rtUboFromImage(params->width, params->height, &ubo) != RT_OK)
+            return fail(ctx, RT_ERR_INVALID, "rtRender: bad image size");
+        return rtRenderUbo(ctx, &ubo, params->mode, dst, dst_pitch, dst_is_device, stream);
+    }
+    if (params->mode != RT_MODE_PATH) return fail(ctx, RT_ERR_INVALID, "rtRender: unknown mode");
+    if (!cam) return fail(ctx, RT_ERR_INVALID, "rtRender: cam is null");
+    if (ctx->n_spheres == 0) return fail(ctx, RT_ERR_STATE, "rtRender: PATH mode needs rtSetScene first");
+    if (params->width < 2 || params->height < 2)
+        return fail(ctx, RT_ERR_INVALID, "rtRender: PATH mode needs width,height >= 2");
+    if (params->spp == 0) return fail(ctx, RT_ERR_INVALID, "rtRender: spp must be >= 1");
+    if (params->quantiser > RT_QUANT_BOOK) return fail(ctx, RT_ERR_INVALID, "rtRender: unknown quantiser");
+    return render_common(ctx, false, nullptr, cam, params, dst, dst_pitch, dst_is_device, stream);
+}
+
+int rtRenderUbo(RtContext* ctx, const RtUbo5* ubo, uint32_t mode, void* dst, size_t dst_pitch,
+                int dst_is_device, void* stream) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rtRenderUbo: ctx is null");
+    if (!ubo) return fail(ctx, RT_ERR_INVALID, "rtRenderUbo: ubo is null");
+    if (mode != RT_MODE_CH05 && mode != RT_MODE_CH06)
+        return fail(ctx, RT_ERR_INVALID, "rtRenderUbo: mode must be RT_MODE_CH05 or RT_MODE_CH06");
+    if (!(ubo->imageWidth >= 1.0f) || !(ubo->imageHeight >= 1.0f) || ubo->imageWidth > 65536.0f ||
+        ubo->imageHeight > 65536.0f)
+        return fail(ctx, RT_ERR_INVALID, "rtRenderUbo: image size out of range");
+    RtParams p{};
+    // main.cpp:106: the image extent is the UBO's float size truncated to uint32_t
+    p.width = static_cast<uint32_t>(ubo->imageWidth);
+    p.height = static_cast<uint32_t>(ubo->imageHeight);
+    p.mode = mode;
+    p.spp = 1;
+    return render_common(ctx, true, ubo, nullptr, &p, dst, dst_pitch, dst_is_device, stream);
+}
+
+int rtSynchronize(RtContext* ctx) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rtSynchronize: ctx is null");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->last_stream ? ctx->last_stream : ctx->stream));
+    return RT_OK;
+}
+
+int rtGetStats(RtContext* ctx, RtStats* out) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rtGetStats: ctx is null");
+    if (!out) return fail(ctx, RT_ERR_INVALID, "rtGetStats: out is null");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->have_timing) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->last_stream ? ctx->last_stream : ctx->stream));
+        float ms = 0.0f;
+        RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+        ctx->stats.kernel_ms = ms;
+        ctx->stats.paths = ctx->h_counters->paths;
+        ctx->stats.segments = ctx->h_counters->segments;
+        ctx->stats.sphere_tests = ctx->stats.segments * ctx->stats.n_spheres;
+    }
+    *out = ctx->stats;
+    return RT_OK;
+}
+
+// Arithmetic conformance probe: runs op over host arrays on the GPU
+// (0 fma, 1 div, 2 sqrt, 3 mul, 4 add, 5 RNG draw).  Used by the parity tests to
+// localise any CPU/GPU rounding difference to a single operation.
+int rtSelfTestArith(RtContext* ctx, uint32_t op, const float* a, const float* b, const float* c,
+                    float* out, uint32_t n) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rtSelfTestArith: ctx is null");
+    if (!a || !b || !c || !out || n == 0 || op > 5)
+        return fail(ctx, RT_ERR_INVALID, "rtSelfTestArith: bad arguments");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    float* d = nullptr;
+    const size_t bytes = size_t(n) * sizeof(float);
+    RT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d), bytes * 4));
+    hipError_t e = hipMemcpy(d, a, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n, b, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + 2 * size_t(n), c, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rtiow::launch_arith(op, d, d + n, d + 2 * size_t(n), d + 3 * size_t(n), n, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d + 3 * size_t(n), bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail_hip(ctx, e, "rtSelfTestArith");
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// rtiow_device.h — launch interface between the C ABI (rtiow_capi.hip) and the
+// gfx950 kernels (rtiow_kernels.hip).  Internal; not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "../../include/rtiow.h"
+
+namespace rtiow {
+
+// Device-side counters, one block per context (zeroed before every render).
+struct Counters {
+    unsigned long long paths;
+    unsigned long long segments;
+    unsigned long long queue_head;  // persistent kernel: next chunk id
+    unsigned long long pad;
+};
+
+struct PathArgs {
+    const float4* spheres;       // n x {cx,cy,cz,radius} as uploaded (RtSphere)
+    const RtMaterial* materials; // n x 32 B
+    uint32_t n;
+    RtCamera cam;
+    uint32_t width, height;      // full image
+    uint32_t spp, max_depth, seed, quantiser;
+    uint32_t chunk_spp;          // normalised: 1..spp
+    uint32_t row_block, tile_rank, tile_count;
+    uint32_t local_rows;         // rows this call renders
+    uint32_t* dst;               // local_rows x dst_stride words
+    uint32_t dst_stride;         // in 32-bit words
+    float4* partials;            // persistent kernel: local_pixels x chunks partial sums
+    Counters* counters;
+};
+
+struct ChArgs {
+    RtUbo5 ubo;
+    uint32_t mode;
+    uint32_t width, height;
+    uint32_t* dst;
+    uint32_t dst_stride;
+};
+
+// kernel variants selectable through RtParams.kernel (identical results)
+enum : uint32_t {
+    KERNEL_DEFAULT = 0,
+    KERNEL_PIXEL = 1,      // one lane per pixel, spp loop inside (v1)
+    KERNEL_PERSISTENT = 2  // persistent waves + chunk queue + ballot refill (v2)
+};
+
+hipError_t launch_ch(const ChArgs& a, hipStream_t stream);
+hipError_t launch_path(const PathArgs& a, uint32_t kernel, int num_cus, hipStream_t stream);
+size_t path_partials_bytes(const PathArgs& a, uint32_t kernel);
+hipError_t launch_arith(uint32_t op, const float* a, const float* b, const float* c, float* out,
+                        uint32_t n, hipStream_t stream);
+
+}  // namespace rtiow

@@ -1,0 +1,57 @@
+"""Row-tile partition of a frame across the GPUs of one node and the framebuffer
+gather over RCCL (the reference is single-device:
+RTCHAP06/Vulkan.cpp:87-97,122).
+
+One process per GPU.  Rank r renders the rows with (row // row_block) % world == r
+(block-cyclic: sky rows are far cheaper than sphere-dense rows, so contiguous
+bands would leave the sky ranks idle), packed in ascending order, into its own
+HBM buffer; nothing is exchanged while rendering.  The only collective is one
+gather of the finished RGBA8 rows to the root, followed by a de-interleave.
+Pixels do not depend on the partition (RNG keyed by the global pixel index), so
+1/2/4/8-GPU frames are byte-identical.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def tile_rows(height: int, row_block: int, rank: int, world: int) -> np.ndarray:
+    """Global row indices rank `rank` renders, ascending (== rtTileGlobalRow over its local rows)."""
+    if world <= 1:
+        return np.arange(height, dtype=np.int64)
+    row_block = max(1, int(row_block))
+    rows = np.arange(height, dtype=np.int64)
+    return rows[(rows // row_block) % world == rank]
+
+
+def max_tile_rows(height: int, row_block: int, world: int) -> int:
+    return max(len(tile_rows(height, row_block, r, world)) for r in range(max(1, world)))
+
+
+def gather_frame(local: torch.Tensor, height: int, row_block: int, rank: int, world: int,
+                 dst: int = 0, group=None) -> Optional[torch.Tensor]:
+    """Gathers every rank's packed rows ([rows_r, width] int32, RGBA8 packed) to `dst` and
+    returns the assembled [height, width] frame there (None elsewhere)."""
+    if world <= 1:
+        return local
+    width = local.shape[1]
+    pad_rows = max_tile_rows(height, row_block, world)
+    send = local
+    if local.shape[0] != pad_rows:  # equal counts for the collective: pad the short tiles
+        send = torch.zeros((pad_rows, width), dtype=local.dtype, device=local.device)
+        send[: local.shape[0]] = local
+    send = send.contiguous()
+    if rank == dst:
+        parts = [torch.empty_like(send) for _ in range(world)]
+        dist.gather(send, gather_list=parts, dst=dst, group=group)
+        frame = torch.empty((height, width), dtype=local.dtype, device=local.device)
+        for r in range(world):
+            rows = torch.from_numpy(tile_rows(height, row_block, r, world)).to(local.device)
+            frame.index_copy_(0, rows, parts[r][: len(rows)])
+        return frame
+    dist.gather(send, gather_list=None, dst=dst, group=group)
+    return None
