@@ -45,20 +45,36 @@ def build_scene(V, scene, grid_half, w, h):
     return sph, mat, cam
 
 
+def usable_cores(reported):
+    """Host cores this process may actually use: min(OpenMP's count, affinity mask, cgroup quota)."""
+    n = reported
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(V, sph, mat, cam, w, h, spp, depth, chunk, target_s=15.0):
     """Times the CPU oracle (kind "port": the reference has no CPU path) on a bounded sample:
     every k-th row of the same frame, all host cores, sized for ~target_s seconds."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_bind
     orc = oracle_bind.load()
-    cores = orc.num_procs()
+    cores = usable_cores(orc.num_procs())
     # probe: 4 evenly spread rows
     probe_rows = 4
     stride = max(1, h // probe_rows)
     prm = V.make_params(w, h, spp=spp, max_depth=depth, seed=1, chunk_spp=chunk, row_block=1,
                         tile_rank=0, tile_count=stride)
     t0 = time.perf_counter()
-    img, _ = orc.render(sph, mat, cam, prm)
+    img, _ = orc.render(sph, mat, cam, prm, nthreads=cores)
     probe_t = time.perf_counter() - t0
     per_row = probe_t / max(1, img.shape[0])
     rows = int(min(h, max(probe_rows, target_s / max(per_row, 1e-9))))
@@ -66,7 +82,7 @@ def cpu_baseline(V, sph, mat, cam, w, h, spp, depth, chunk, target_s=15.0):
     prm = V.make_params(w, h, spp=spp, max_depth=depth, seed=1, chunk_spp=chunk, row_block=1,
                         tile_rank=0, tile_count=stride)
     t0 = time.perf_counter()
-    img, segs = orc.render(sph, mat, cam, prm)
+    img, segs = orc.render(sph, mat, cam, prm, nthreads=cores)
     dt = time.perf_counter() - t0
     n_rows = img.shape[0]
     return {
@@ -121,7 +137,12 @@ def main():
                         kernel=args.kernel)
     rows = V.tile_row_count(h, prm.row_block, prm.tile_rank, prm.tile_count)
     local = torch.zeros((rows, w), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    # a real (non-null) torch stream: the kernels, the timing events and the RCCL gather are all
+    # ordered on it (a NULL handle would mean "the context's own stream" to the C ABI)
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
 
     def step():
         ctx.render_device(cam, prm, local.data_ptr(), w * 4, stream)

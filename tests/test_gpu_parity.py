@@ -163,9 +163,12 @@ def test_device_destination_and_pitch(gpu_ctx, oracle):
     want = gpu_ctx.render(cam, prm)
     pitch_px = 64
     buf = torch.full((h, pitch_px), 0x7F7F7F7F, dtype=torch.int32, device="cuda:0")
-    stream = torch.cuda.current_stream().cuda_stream
-    gpu_ctx.render_device(cam, prm, buf.data_ptr(), pitch_px * 4, stream)
-    torch.cuda.synchronize()
+    ts = torch.cuda.Stream()
+    ts.wait_stream(torch.cuda.current_stream())   # buf's fill
+    with torch.cuda.stream(ts):
+        gpu_ctx.render_device(cam, prm, buf.data_ptr(), pitch_px * 4, ts.cuda_stream)
+    ts.synchronize()
+    assert gpu_ctx.stats().kernel_ms > 0
     host = buf.cpu().numpy().view(np.uint8).reshape(h, pitch_px, 4)
     assert np.array_equal(host[:, :w], want)
     assert (host[:, w:] == 0x7F).all()   # padding untouched

@@ -333,6 +333,234 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 }
 
 // ============================================================================
+// PATH v2: persistent waves, chunk queue, ballot refill, candidate bitmasks
+// ============================================================================
+//
+// Work item = one chunk: chunk_spp consecutive samples of one pixel, summed
+// sequentially into one partial sum (the pixel is the sequential sum of its
+// partial sums, resolved by resolve_kernel: the order is part of the spec, so
+// the frame does not depend on which lane traced what).  Every lane owns R
+// path slots.  One loop iteration traces exactly one segment per live slot:
+//
+//   refill   slots whose path ended start the next sample of their chunk; slots
+//            whose chunk is finished store its partial sum and pull a new chunk:
+//            __ballot of the needy lanes, ONE atomicAdd per wave on the queue
+//            head, ids handed out by mbcnt prefix — dead lanes are refilled
+//            immediately, so the sphere loop always runs with full waves.
+//   trace    all lanes walk the LDS sphere list in lock-step (broadcast reads),
+//            branch-free: 11 VALU per ray-sphere test, the sign bit of the
+//            discriminant shifted into a per-lane candidate word by one
+//            v_alignbit.  Only candidates (a handful per ray) take the
+//            sqrt/root path, per lane, after each block of 32 spheres.
+//   shade    miss -> sky into the partial sum; hit -> scatter by material.
+//
+// Order-independence: the closest hit is the minimum over spheres of each
+// sphere's first root in (t_min, inf), ties to the lowest index — exactly what
+// the oracle's sequential scan computes — so candidates may be examined in any
+// grouping.
+
+constexpr int kSlots = 2;          // path slots per lane
+constexpr uint32_t kBlockSph = 32; // spheres per candidate word
+
+struct Slot {
+    Path p;
+    f3 part;               // partial sum of the current chunk
+    uint32_t pix;          // local pixel index
+    uint32_t s, s_end;     // next sample, end of chunk
+    uint32_t chunk;        // chunk id (index into partials)
+    uint32_t depth;
+    bool active, has_chunk;
+};
+
+DI void examine_candidate(const float4* lds, uint32_t j, uint32_t n, const Path& p, float& best,
+                          int& best_i) {
+    if (j >= n) return;  // list padding
+    const float4 s = lds[j];
+    const float ocx = p.o.x - s.x, ocy = p.o.y - s.y, ocz = p.o.z - s.z;
+    const float hb = fma_(ocz, p.du.z, fma_(ocy, p.du.y, ocx * p.du.x));
+    const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
+    const float disc = fma_(hb, hb, -cc);
+    if (__builtin_signbit(disc) || disc != disc) return;
+    const float sq = __builtin_sqrtf(disc);
+    float root = -hb - sq;
+    if (!(root > kTMin && root < best)) {
+        root = -hb + sq;
+        if (!(root > kTMin && root < best)) return;
+    }
+    // ascending j within a slot: a tie keeps the earlier (lower) index
+    best = root;
+    best_i = static_cast<int>(j);
+}
+
+template <int R>
+DI void trace_slots(const float4* lds, uint32_t n_pad, uint32_t n, Slot (&sl)[R], float (&best)[R],
+                    int (&best_i)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        best[r] = __builtin_inff();
+        best_i[r] = -1;
+    }
+    for (uint32_t base = 0; base < n_pad; base += kBlockSph) {
+        uint32_t miss[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) miss[r] = 0u;
+#pragma unroll 8
+        for (uint32_t j = 0; j < kBlockSph; ++j) {
+            const float4 s = lds[base + j];  // wave-uniform address: LDS broadcast
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const Path& p = sl[r].p;
+                const float ocx = p.o.x - s.x, ocy = p.o.y - s.y, ocz = p.o.z - s.z;
+                const float hb = fma_(ocz, p.du.z, fma_(ocy, p.du.y, ocx * p.du.x));
+                const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
+                const float disc = fma_(hb, hb, -cc);
+                // shift the sign bit in: 1 = certainly no hit
+                miss[r] = __builtin_amdgcn_alignbit(miss[r], __float_as_uint(disc), 31);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uint32_t cand = sl[r].active ? ~miss[r] : 0u;
+            while (cand) {
+                const uint32_t bit = static_cast<uint32_t>(__builtin_clz(cand));
+                cand &= ~(0x80000000u >> bit);
+                examine_candidate(lds, base + bit, n, sl[r].p, best[r], best_i[r]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, uint32_t n_pad,
+                                                              uint32_t chunks_per_pixel,
+                                                              unsigned long long total_chunks) {
+    extern __shared__ float4 lds_spheres[];
+    for (uint32_t i = threadIdx.x; i < n_pad; i += blockDim.x) {
+        float4 s;
+        if (i < a.n) {
+            s = a.spheres[i];
+            s.w = s.w * s.w;
+        } else {
+            s = make_float4(0.0f, 0.0f, 0.0f, -1.0f);  // padding: disc = hb^2 - |o|^2 - 1 < 0
+        }
+        lds_spheres[i] = s;
+    }
+    __syncthreads();
+
+    Slot sl[kSlots];
+#pragma unroll
+    for (int r = 0; r < kSlots; ++r) {
+        sl[r].active = false;
+        sl[r].has_chunk = false;
+        sl[r].part = mk(0.0f, 0.0f, 0.0f);
+        sl[r].pix = sl[r].s = sl[r].s_end = sl[r].chunk = sl[r].depth = 0u;
+        sl[r].p.o = sl[r].p.du = sl[r].p.att = mk(0.0f, 0.0f, 0.0f);
+    }
+    bool exhausted = false;  // wave-uniform: the queue has been drained
+    uint32_t n_paths = 0, n_segments = 0;
+
+    for (;;) {
+        // ---- refill ---------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < kSlots; ++r) {
+            Slot& q = sl[r];
+            bool need = !q.active && (!q.has_chunk || q.s == q.s_end);
+            if (need && q.has_chunk) {
+                a.partials[q.chunk] = make_float4(q.part.x, q.part.y, q.part.z, 0.0f);
+                q.has_chunk = false;
+            }
+            if (!exhausted) {
+                const unsigned long long mask = __ballot(need);
+                if (mask != 0ull) {
+                    const uint32_t want = static_cast<uint32_t>(__popcll(mask));
+                    unsigned long long base = 0ull;
+                    if (__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                            __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u)) == 0u && need)
+                        base = atomicAdd(&a.counters->queue_head, static_cast<unsigned long long>(want));
+                    // broadcast from the first needy lane
+                    const int leader = __builtin_ctzll(mask);
+                    const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(base), leader);
+                    const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(base >> 32), leader);
+                    base = (static_cast<unsigned long long>(hi) << 32) | lo;
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
+                        static_cast<uint32_t>(mask >> 32),
+                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+                    const unsigned long long id = base + rank;
+                    if (need && id < total_chunks) {
+                        q.chunk = static_cast<uint32_t>(id);
+                        q.pix = static_cast<uint32_t>(id / chunks_per_pixel);
+                        const uint32_t k = static_cast<uint32_t>(id % chunks_per_pixel);
+                        q.s = k * a.chunk_spp;
+                        q.s_end = (q.s + a.chunk_spp < a.spp) ? q.s + a.chunk_spp : a.spp;
+                        q.part = mk(0.0f, 0.0f, 0.0f);
+                        q.has_chunk = true;
+                    }
+                    if (base + want >= total_chunks) exhausted = true;
+                }
+            }
+            if (!q.active && q.has_chunk) {  // next sample of the chunk
+                const uint32_t lr = q.pix / a.width, i = q.pix % a.width;
+                const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
+                camera_path(a, i, j, q.s, q.p);
+                ++q.s;
+                q.depth = 0u;
+                q.active = true;
+                ++n_paths;
+            }
+        }
+        bool any_active = false;
+#pragma unroll
+        for (int r = 0; r < kSlots; ++r) any_active = any_active || sl[r].active;
+        if (__ballot(any_active) == 0ull) break;  // queue drained and every path finished
+
+        // ---- trace ----------------------------------------------------------
+        float best[kSlots];
+        int best_i[kSlots];
+        trace_slots<kSlots>(lds_spheres, n_pad, a.n, sl, best, best_i);
+
+        // ---- shade ----------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < kSlots; ++r) {
+            Slot& q = sl[r];
+            if (!q.active) continue;
+            ++n_segments;
+            if (best_i[r] < 0) {
+                const f3 rad = sky_radiance(q.p);
+                q.part = mk(q.part.x + rad.x, q.part.y + rad.y, q.part.z + rad.z);
+                q.active = false;
+            } else if (!scatter(a, best_i[r], best[r], q.p)) {
+                q.active = false;  // absorbed: radiance 0
+            } else if (++q.depth >= a.max_depth) {
+                q.active = false;  // depth exhausted: radiance 0
+            }
+        }
+    }
+
+    // one counter update per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        n_paths += __shfl_down(n_paths, off);
+        n_segments += __shfl_down(n_segments, off);
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        atomicAdd(&a.counters->paths, static_cast<unsigned long long>(n_paths));
+        atomicAdd(&a.counters->segments, static_cast<unsigned long long>(n_segments));
+    }
+}
+
+// partial sums -> RGBA8, one lane per pixel (coalesced 4-byte stores: 256 B per wave)
+__global__ __launch_bounds__(256) void resolve_kernel(PathArgs a, uint32_t chunks_per_pixel) {
+    const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lp >= a.local_rows * a.width) return;
+    f3 sum = mk(0.0f, 0.0f, 0.0f);
+    const float4* part = a.partials + static_cast<size_t>(lp) * chunks_per_pixel;
+    for (uint32_t k = 0; k < chunks_per_pixel; ++k) {
+        const float4 v = part[k];
+        sum = mk(sum.x + v.x, sum.y + v.y, sum.z + v.z);
+    }
+    const uint32_t lr = lp / a.width, i = lp % a.width;
+    a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = resolve_pixel(sum, a.spp, a.quantiser);
+}
+
+// ============================================================================
 // arithmetic conformance probe (tests/test_gpu_arith.py)
 // ============================================================================
 __global__ void arith_kernel(uint32_t op, const float* a, const float* b, const float* c,
@@ -364,13 +592,52 @@ hipError_t launch_ch(const ChArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-size_t path_partials_bytes(const PathArgs&, uint32_t) { return 0; }
+static uint32_t chunks_per_pixel(const PathArgs& a) { return (a.spp + a.chunk_spp - 1u) / a.chunk_spp; }
 
-hipError_t launch_path(const PathArgs& a, uint32_t kernel, int /*num_cus*/, hipStream_t stream) {
-    (void)kernel;
-    const uint32_t tiles = ((a.width + 15u) / 16u) * ((a.local_rows + 15u) / 16u);
-    const size_t lds = static_cast<size_t>(a.n) * sizeof(float4);
-    hipLaunchKernelGGL(path_pixel_kernel, dim3(tiles), dim3(256), lds, stream, a);
+static bool use_persistent(uint32_t kernel) { return kernel != KERNEL_PIXEL; }
+
+size_t path_partials_bytes(const PathArgs& a, uint32_t kernel) {
+    if (!use_persistent(kernel)) return 0;
+    return static_cast<size_t>(a.local_rows) * a.width * chunks_per_pixel(a) * sizeof(float4);
+}
+
+hipError_t launch_path(const PathArgs& a, uint32_t kernel, int num_cus, hipStream_t stream) {
+    if (!use_persistent(kernel)) {
+        const uint32_t tiles = ((a.width + 15u) / 16u) * ((a.local_rows + 15u) / 16u);
+        const size_t lds = static_cast<size_t>(a.n) * sizeof(float4);
+        if (lds > 48u * 1024u) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(path_pixel_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(path_pixel_kernel, dim3(tiles), dim3(256), lds, stream, a);
+        return hipGetLastError();
+    }
+    const uint32_t n_pad = (a.n + kBlockSph - 1u) / kBlockSph * kBlockSph;
+    const size_t lds = static_cast<size_t>(n_pad) * sizeof(float4);
+    // one LDS copy of the list per workgroup: small lists -> 256-thread groups (8 per CU);
+    // large lists -> 1024-thread groups so 16 waves share one copy
+    const uint32_t threads = lds <= 16u * 1024u ? 256u : 1024u;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(path_persistent_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_persistent_kernel, static_cast<int>(threads), lds);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    const uint32_t cpp = chunks_per_pixel(a);
+    const unsigned long long total = static_cast<unsigned long long>(a.local_rows) * a.width * cpp;
+    // persistent grid: fill the chip once; never more lanes than work items
+    unsigned long long want_blocks = (total + threads * kSlots - 1) / (threads * kSlots);
+    unsigned long long grid = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256) * per_cu;
+    if (grid > want_blocks) grid = want_blocks;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(path_persistent_kernel, dim3(static_cast<uint32_t>(grid)), dim3(threads), lds, stream, a,
+                       n_pad, cpp, total);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const uint32_t px = a.local_rows * a.width;
+    hipLaunchKernelGGL(resolve_kernel, dim3((px + 255u) / 256u), dim3(256), 0, stream, a, cpp);
     return hipGetLastError();
 }
 
