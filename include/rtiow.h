@@ -98,14 +98,15 @@ typedef struct RtCamera {
 typedef struct RtParams {
     uint32_t width;      /* full image width                                        */
     uint32_t height;     /* full image height                                       */
-    uint32_t spp;        /* samples per pixel (PATH)                                */
+    uint32_t spp;        /* samples per pixel (PATH), 1..65536                      */
     uint32_t max_depth;  /* bounce limit (PATH)                                     */
     uint32_t seed;       /* RNG seed (PATH)                                         */
     uint32_t mode;       /* RT_MODE_*                                               */
     uint32_t quantiser;  /* RT_QUANT_*                                              */
-    uint32_t chunk_spp;  /* samples summed sequentially per partial sum; the pixel
-                            is the sequential sum of its partial sums.  0 or >= spp
-                            means one chunk (the book's plain loop).               */
+    uint32_t chunk_spp;  /* scheduling hint only: the most samples a lane takes from the
+                            work queue at a time (0 = auto).  Never changes the image:
+                            samples are accumulated in 32.32 fixed point, an integer
+                            sum that is independent of order and grouping.             */
     /* Row tiling across GPUs: this call renders the rows r with
      * (r / row_block) % tile_count == tile_rank, packed in ascending order.
      * tile_count == 0 or 1 renders the whole image. */
@@ -124,6 +125,7 @@ typedef struct RtStats {
     uint64_t bytes_written;  /* algorithmic framebuffer bytes of the last render          */
     uint32_t rows_rendered;
     uint32_t n_spheres;
+    uint64_t debug[8];       /* kernel-internal counters of diagnostic builds (0 otherwise)   */
 } RtStats;
 
 typedef struct RtContext RtContext;
@@ -162,7 +164,7 @@ int rtSynchronize(RtContext* ctx);
 
 /* Arithmetic conformance probe (diagnostic): evaluates one operation per
  * element on the GPU over host arrays — op 0 fma(a,b,c), 1 a/b, 2 sqrt(a),
- * 3 a*b, 4 a+b, 5 RNG draw — so a CPU/GPU rounding difference can be pinned to
+ * 3 a*b, 4 a+b, 5 RNG draw, 6 fixed-point accumulate, 7 u64->float — so a CPU/GPU rounding difference can be pinned to
  * a single operation.  No reference counterpart. */
 int rtSelfTestArith(RtContext* ctx, uint32_t op, const float* a, const float* b, const float* c,
                     float* out, uint32_t n);

@@ -73,23 +73,53 @@ static inline float randf(uint32_t* st) { /* [0,1), 24 bits */
     *st = pcg_step(*st);
     return (float)(pcg_out(*st) >> 8) * 0x1p-24f;
 }
-static inline float rand_pm1(uint32_t* st) { return 2.0f * randf(st) - 1.0f; }
 
-static v3 random_in_unit_sphere(uint32_t* st) { /* rejection from [-1,1)^3 */
-    for (;;) {
-        v3 p;
-        p.x = rand_pm1(st);
-        p.y = rand_pm1(st);
-        p.z = rand_pm1(st);
-        if (vdot(p, p) < 1.0f) return p;
+/* Rejection-free sampling (BUILD-SPEC).  The book draws points by rejection from a
+ * cube/square; on a 64-wide SIMD the trip count of a rejection loop is the maximum
+ * over the lanes, so the spec uses closed forms built from + - * sqrt and fma only.
+ * sincos_2pi: quadrant from the top two bits of u, then two polynomials in
+ * f = frac(4u) for sin(pi/2 f), cos(pi/2 f) (max abs error 2e-7), fma-only so that
+ * CPU and GPU agree bit for bit. */
+static const float kS0 = 0x1.921fb6p+0f, kS1 = -0x1.4abbc4p-1f, kS2 = 0x1.4668f0p-4f,
+                   kS3 = -0x1.32533cp-8f, kS4 = 0x1.3e15f6p-13f;
+static const float kC0 = 0x1.fffffep-1f, kC1 = -0x1.3bd3a6p+0f, kC2 = 0x1.03bd02p-2f,
+                   kC3 = -0x1.54f5dcp-6f, kC4 = 0x1.c1ecap-11f;
+
+static void sincos_2pi(float u, float* c, float* s) { /* u in [0,1) */
+    float t = 4.0f * u;          /* exact */
+    int q = (int)t;              /* 0..3 */
+    float f = t - (float)q;      /* exact */
+    float f2 = f * f;
+    float sp = f * fmaf(f2, fmaf(f2, fmaf(f2, fmaf(f2, kS4, kS3), kS2), kS1), kS0);
+    float cp = fmaf(f2, fmaf(f2, fmaf(f2, fmaf(f2, kC4, kC3), kC2), kC1), kC0);
+    switch (q) {
+        case 0: *c = cp; *s = sp; break;
+        case 1: *c = -sp; *s = cp; break;
+        case 2: *c = -cp; *s = -sp; break;
+        default: *c = sp; *s = -cp; break;
     }
 }
+
+/* uniform direction: z uniform in (-1,1], azimuth uniform; two draws, no rejection */
+static v3 random_unit_vector(uint32_t* st) {
+    float u1 = randf(st);
+    float u2 = randf(st);
+    float z = 1.0f - 2.0f * u1;
+    float r = sqrtf(fmaf(-z, z, 1.0f));
+    float c, s;
+    sincos_2pi(u2, &c, &s);
+    return V(r * c, r * s, z);
+}
+
+/* uniform point in the unit disk: radius sqrt(u1), azimuth 2 pi u2 */
 static void random_in_unit_disk(uint32_t* st, float* dx, float* dy) {
-    for (;;) {
-        float x = rand_pm1(st);
-        float y = rand_pm1(st);
-        if (fmaf(y, y, x * x) < 1.0f) { *dx = x; *dy = y; return; }
-    }
+    float u1 = randf(st);
+    float u2 = randf(st);
+    float r = sqrtf(u1);
+    float c, s;
+    sincos_2pi(u2, &c, &s);
+    *dx = r * c;
+    *dy = r * s;
 }
 
 /* ---- quantisers (a5 / a10) ---------------------------------------------- */
@@ -250,14 +280,14 @@ static v3 ray_color(const Scene* sc, v3 o, v3 du, uint32_t* st, uint64_t* segs) 
         const RtSphere* sp = &sc->sph[i];
         const RtMaterial* m = &sc->mat[i];
         v3 p = V(fmaf(s, du.x, o.x), fmaf(s, du.y, o.y), fmaf(s, du.z, o.z));
-        v3 on = V((p.x - sp->cx) / sp->radius, (p.y - sp->cy) / sp->radius,
-                  (p.z - sp->cz) / sp->radius);
+        float inv_r = 1.0f / sp->radius; /* negative radius flips the normal (hollow glass) */
+        v3 on = V((p.x - sp->cx) * inv_r, (p.y - sp->cy) * inv_r, (p.z - sp->cz) * inv_r);
         float dn = vdot(du, on);
         int front = dn < 0.0f;
         v3 n = front ? on : vneg(on);
         v3 dir;
         if (m->kind == RT_MAT_LAMBERTIAN) {
-            v3 rv = vunit(random_in_unit_sphere(st)); /* random_unit_vector */
+            v3 rv = random_unit_vector(st);
             dir = vadd(n, rv);
             if (fabsf(dir.x) < 1e-8f && fabsf(dir.y) < 1e-8f && fabsf(dir.z) < 1e-8f) dir = n;
             att = V(att.x * m->albedo[0], att.y * m->albedo[1], att.z * m->albedo[2]);
@@ -265,8 +295,8 @@ static v3 ray_color(const Scene* sc, v3 o, v3 du, uint32_t* st, uint64_t* segs) 
             float k2 = 2.0f * vdot(du, n);
             v3 refl = V(fmaf(-k2, n.x, du.x), fmaf(-k2, n.y, du.y), fmaf(-k2, n.z, du.z));
             dir = refl;
-            if (m->fuzz > 0.0f) {
-                v3 rs = random_in_unit_sphere(st);
+            if (m->fuzz > 0.0f) { /* book v4: reflected + fuzz * random_unit_vector() */
+                v3 rs = random_unit_vector(st);
                 dir = V(fmaf(m->fuzz, rs.x, refl.x), fmaf(m->fuzz, rs.y, refl.y),
                         fmaf(m->fuzz, rs.z, refl.z));
             }
@@ -307,8 +337,10 @@ static v3 ray_color(const Scene* sc, v3 o, v3 du, uint32_t* st, uint64_t* segs) 
 static v3 sample_pixel(const Scene* sc, uint32_t i, uint32_t j, uint32_t s, uint64_t* segs) {
     const RtCamera* c = &sc->cam;
     uint32_t st = rng_init(sc->p.seed, j * sc->p.width + i, s);
-    float u = ((float)i + randf(&st)) / (float)(sc->p.width - 1);
-    float v = ((float)j + randf(&st)) / (float)(sc->p.height - 1);
+    /* same /(W-1) convention as raytrace06.comp:57-58, as a multiply by the rounded reciprocal */
+    float inv_wm1 = 1.0f / (float)(sc->p.width - 1), inv_hm1 = 1.0f / (float)(sc->p.height - 1);
+    float u = ((float)i + randf(&st)) * inv_wm1;
+    float v = ((float)j + randf(&st)) * inv_hm1;
     v3 off = V(0, 0, 0);
     if (c->lens_radius > 0.0f) {
         float dx, dy;
@@ -325,18 +357,28 @@ static v3 sample_pixel(const Scene* sc, uint32_t i, uint32_t j, uint32_t s, uint
     return ray_color(sc, o, vunit(d), &st, segs);
 }
 
+/* Multi-sample accumulate (a10).  BUILD-SPEC: every sample's radiance component is
+ * converted to unsigned 32.32 fixed point (clamp to [0, 32768], multiply by 2^32 —
+ * exact — and truncate) and the pixel is the INTEGER sum of its samples, so the sum
+ * does not depend on the order or grouping in which samples are added (a GPU may
+ * split a pixel's samples over lanes and combine them with integer atomics).
+ * write_color: c = sqrt((float)sum * (1 / (spp * 2^32))), then the quantiser. */
+static inline uint64_t to_fixed(float x) {
+    float c = (x > 0.0f) ? (x < 32768.0f ? x : 32768.0f) : 0.0f; /* NaN -> 0 */
+    return (uint64_t)(c * 4294967296.0f);
+}
+
 static uint32_t path_pixel(const Scene* sc, uint32_t i, uint32_t j, uint64_t* segs) {
     uint32_t spp = sc->p.spp;
-    uint32_t chunk = (sc->p.chunk_spp == 0 || sc->p.chunk_spp > spp) ? spp : sc->p.chunk_spp;
-    v3 sum = V(0, 0, 0);
-    for (uint32_t s0 = 0; s0 < spp; s0 += chunk) {
-        uint32_t s1 = s0 + chunk < spp ? s0 + chunk : spp;
-        v3 part = V(0, 0, 0);
-        for (uint32_t s = s0; s < s1; s++) part = vadd(part, sample_pixel(sc, i, j, s, segs));
-        sum = vadd(sum, part);
+    uint64_t sr = 0, sg = 0, sb = 0;
+    for (uint32_t s = 0; s < spp; s++) {
+        v3 c = sample_pixel(sc, i, j, s, segs);
+        sr += to_fixed(c.x);
+        sg += to_fixed(c.y);
+        sb += to_fixed(c.z);
     }
-    float scale = 1.0f / (float)spp;
-    float r = sqrtf(scale * sum.x), g = sqrtf(scale * sum.y), b = sqrtf(scale * sum.z);
+    float scale = 1.0f / ((float)spp * 4294967296.0f);
+    float r = sqrtf(scale * (float)sr), g = sqrtf(scale * (float)sg), b = sqrtf(scale * (float)sb);
     if (sc->p.quantiser == RT_QUANT_BOOK) return pack_rgba(quant_book(r), quant_book(g), quant_book(b));
     return pack_rgba(quant_unorm8(r), quant_unorm8(g), quant_unorm8(b));
 }
@@ -349,7 +391,7 @@ int oracle_render(const RtSphere* spheres, const RtMaterial* materials, uint32_t
     if (!cam || !params || !dst) return RT_ERR_INVALID;
     if (params->mode != RT_MODE_PATH) return RT_ERR_INVALID;
     if (!spheres || !materials || n == 0) return RT_ERR_STATE;
-    if (params->width < 2 || params->height < 2 || params->spp == 0) return RT_ERR_INVALID;
+    if (params->width < 2 || params->height < 2 || params->spp == 0 || params->spp > 65536) return RT_ERR_INVALID;
     if (pitch < (size_t)params->width * 4) return RT_ERR_INVALID;
     Scene sc;
     sc.sph = spheres; sc.mat = materials; sc.n = n; sc.cam = *cam; sc.p = *params;
@@ -539,8 +581,9 @@ int oracle_write_ppm(const char* path, const uint8_t* rgba8, uint32_t W, uint32_
 }
 
 /* ---- arithmetic conformance probes (CPU side of tests/test_arith_gpu.py) ---
- * op: 0 fma(a,b,c) 1 a/b 2 sqrt(a) 3 a*b 4 a+b 5 rng: pcg stream draw #b of
- * (seed=a bits, pixel=c bits) */
+ * op: 0 fma(a,b,c) 1 a/b 2 sqrt(a) 3 a*b 4 a+b 5 rng: 4th draw of stream (seed=a bits,
+ * pixel=c bits, sample 7) 6 (float)(to_fixed(a)+to_fixed(b)) [fixed-point accumulate +
+ * u64->float rounding] 7 (float)(u64 built from the bits of a (high) and b (low)) */
 int oracle_arith(uint32_t op, const float* a, const float* b, const float* c, float* out,
                  uint32_t n) {
     for (uint32_t i = 0; i < n; i++) {
@@ -558,6 +601,14 @@ int oracle_arith(uint32_t op, const float* a, const float* b, const float* c, fl
                 float r = 0;
                 for (int k = 0; k < 4; k++) r = randf(&st);
                 out[i] = r;
+                break;
+            }
+            case 6: out[i] = (float)(to_fixed(a[i]) + to_fixed(b[i])); break;
+            case 7: {
+                uint32_t hi, lo;
+                memcpy(&hi, &a[i], 4);
+                memcpy(&lo, &b[i], 4);
+                out[i] = (float)(((uint64_t)hi << 32) | lo);
                 break;
             }
             default: return RT_ERR_INVALID;

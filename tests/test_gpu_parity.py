@@ -20,7 +20,8 @@ def _diff(a, b):
 
 
 # ---- arithmetic contract -------------------------------------------------------
-@pytest.mark.parametrize("op,name", [(0, "fma"), (1, "div"), (2, "sqrt"), (3, "mul"), (4, "add"), (5, "rng")])
+@pytest.mark.parametrize("op,name", [(0, "fma"), (1, "div"), (2, "sqrt"), (3, "mul"), (4, "add"), (5, "rng"),
+                                     (6, "fixed_accumulate"), (7, "u64_to_float")])
 def test_arith_bit_exact(gpu_ctx, oracle, op, name):
     """fma / divide / sqrt / RNG on gfx950 == x86, including denormals, zeros and huge values."""
     rng = np.random.default_rng(op)
@@ -35,8 +36,14 @@ def test_arith_bit_exact(gpu_ctx, oracle, op, name):
     c[:k] = special
     if op == 2:
         a = np.abs(a)
-    for arr in (a, b, c):  # NaN/inf payloads are outside the contract
-        arr[~np.isfinite(arr)] = 1.5
+    if op == 6:   # radiance-like magnitudes around the clamp points as well as random bit patterns
+        a[k * k:k * k + 4096] = rng.random(4096, dtype=np.float32) * np.float32(1.5)
+        b[k * k:k * k + 4096] = rng.random(4096, dtype=np.float32) * np.float32(40000.0)
+    if op == 7:   # raw 64-bit patterns: keep a and b as they are (NaN bit patterns are just integers here)
+        a, b = bits[0].view(np.float32).copy(), bits[1].view(np.float32).copy()
+    if op != 7:
+        for arr in (a, b, c):  # NaN/inf payloads are outside the contract
+            arr[~np.isfinite(arr)] = 1.5
     got = gpu_ctx.selftest_arith(op, a, b, c)
     want = oracle.arith(op, a, b, c)
     ok = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))

@@ -15,7 +15,8 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtiow_hip.so")
+# RTIOW_LIB lets a diagnostic build of the same ABI (e.g. -DRTIOW_DEBUG_COUNTERS) stand in
+LIB_PATH = os.environ.get("RTIOW_LIB") or os.path.join(_HERE, "librtiow_hip.so")
 
 # ---- enums (include/rtiow.h) -------------------------------------------------
 RT_OK = 0
@@ -56,7 +57,7 @@ class RtParams(C.Structure):
 class RtStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("paths", C.c_uint64), ("segments", C.c_uint64),
                 ("sphere_tests", C.c_uint64), ("bytes_written", C.c_uint64),
-                ("rows_rendered", C.c_uint32), ("n_spheres", C.c_uint32)]
+                ("rows_rendered", C.c_uint32), ("n_spheres", C.c_uint32), ("debug", C.c_uint64 * 8)]
 
 
 SPHERE_DTYPE = np.dtype([("cx", "<f4"), ("cy", "<f4"), ("cz", "<f4"), ("radius", "<f4")])

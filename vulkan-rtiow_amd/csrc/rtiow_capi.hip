@@ -20,14 +20,14 @@ struct RtContext {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     float4* d_spheres = nullptr;
-    RtMaterial* d_materials = nullptr;
+    rtiow::ShadeRec* d_shade = nullptr;
     uint32_t n_spheres = 0;
     rtiow::Counters* d_counters = nullptr;
     rtiow::Counters* h_counters = nullptr;  // pinned
     uint32_t* d_frame = nullptr;            // staging framebuffer for host destinations
     size_t frame_bytes = 0;
-    float4* d_partials = nullptr;
-    size_t partials_bytes = 0;
+    unsigned long long* d_accum = nullptr;  // fixed-point pixel accumulators
+    size_t accum_bytes = 0;
     bool have_timing = false;
     hipStream_t last_stream = nullptr;
     RtStats stats{};
@@ -120,11 +120,11 @@ int rtDestroy(RtContext* ctx) {
     if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_spheres) (void)hipFree(ctx->d_spheres);
-    if (ctx->d_materials) (void)hipFree(ctx->d_materials);
+    if (ctx->d_shade) (void)hipFree(ctx->d_shade);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
-    if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+    if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -148,25 +148,35 @@ int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materi
     RT_HIP(ctx, hipSetDevice(ctx->device));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_spheres) RT_HIP(ctx, hipFree(ctx->d_spheres));
-    if (ctx->d_materials) RT_HIP(ctx, hipFree(ctx->d_materials));
+    if (ctx->d_shade) RT_HIP(ctx, hipFree(ctx->d_shade));
     ctx->d_spheres = nullptr;
-    ctx->d_materials = nullptr;
+    ctx->d_shade = nullptr;
     ctx->n_spheres = 0;
     RT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_spheres), sizeof(float4) * n_spheres));
-    RT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_materials), sizeof(RtMaterial) * n_spheres));
+    RT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_shade), sizeof(rtiow::ShadeRec) * n_spheres));
     static_assert(sizeof(RtSphere) == sizeof(float4), "RtSphere must be 16 bytes");
-    static_assert(sizeof(RtMaterial) == 32, "RtMaterial must be 32 bytes");
-    // fuzz clamped to [0,1] as the book's metal constructor does
-    RtMaterial* tmp = new (std::nothrow) RtMaterial[n_spheres];
+    static_assert(sizeof(rtiow::ShadeRec) == 32, "ShadeRec must be 32 bytes");
+    rtiow::ShadeRec* tmp = new (std::nothrow) rtiow::ShadeRec[n_spheres];
     if (!tmp) return fail(ctx, RT_ERR_NOMEM, "rtSetScene: out of host memory");
     for (uint32_t i = 0; i < n_spheres; ++i) {
-        tmp[i] = materials[i];
-        if (!(tmp[i].fuzz < 1.0f)) tmp[i].fuzz = 1.0f;
-        if (!(tmp[i].fuzz > 0.0f)) tmp[i].fuzz = 0.0f;
+        rtiow::ShadeRec& r = tmp[i];
+        std::memset(&r, 0, sizeof r);
+        const RtMaterial& m = materials[i];
+        r.kind = m.kind;
+        for (int k = 0; k < 3; ++k) r.albedo[k] = m.albedo[k];
+        if (m.kind == RT_MAT_METAL) {  // fuzz clamped to [0,1] as the book's metal constructor does
+            float fz = m.fuzz;
+            if (!(fz < 1.0f)) fz = 1.0f;
+            if (!(fz > 0.0f)) fz = 0.0f;
+            r.param = fz;
+        } else if (m.kind == RT_MAT_DIELECTRIC) {
+            r.param = m.ior;
+        }
+        r.inv_r = 1.0f / spheres[i].radius;  // IEEE single division, as the oracle's
     }
-    hipError_t e = hipMemcpy(ctx->d_materials, tmp, sizeof(RtMaterial) * n_spheres, hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpy(ctx->d_shade, tmp, sizeof(rtiow::ShadeRec) * n_spheres, hipMemcpyHostToDevice);
     delete[] tmp;
-    if (e != hipSuccess) return fail_hip(ctx, e, "hipMemcpy(materials)");
+    if (e != hipSuccess) return fail_hip(ctx, e, "hipMemcpy(shading records)");
     RT_HIP(ctx, hipMemcpy(ctx->d_spheres, spheres, sizeof(float4) * n_spheres, hipMemcpyHostToDevice));
     ctx->n_spheres = n_spheres;
     return RT_OK;
@@ -221,7 +231,7 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
     } else {
         rtiow::PathArgs a{};
         a.spheres = ctx->d_spheres;
-        a.materials = ctx->d_materials;
+        a.shade = ctx->d_shade;
         a.n = ctx->n_spheres;
         a.cam = *cam;
         a.width = W;
@@ -230,7 +240,8 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         a.max_depth = prm->max_depth;
         a.seed = prm->seed;
         a.quantiser = prm->quantiser;
-        a.chunk_spp = (prm->chunk_spp == 0 || prm->chunk_spp > prm->spp) ? prm->spp : prm->chunk_spp;
+        a.inv_wm1 = 1.0f / static_cast<float>(W - 1);
+        a.inv_hm1 = 1.0f / static_cast<float>(H - 1);
         a.row_block = rblock;
         a.tile_rank = tcount > 1 ? prm->tile_rank : 0u;
         a.tile_count = tcount;
@@ -238,14 +249,13 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         a.dst = out;
         a.dst_stride = out_stride;
         a.counters = ctx->d_counters;
-        const size_t need = rtiow::path_partials_bytes(a, prm->kernel);
+        const size_t need = rtiow::path_accum_bytes(a, prm->kernel);
         if (need) {
-            int rc = ensure_bytes(ctx, reinterpret_cast<void**>(&ctx->d_partials),
-                                  &ctx->partials_bytes, need);
+            int rc = ensure_bytes(ctx, reinterpret_cast<void**>(&ctx->d_accum), &ctx->accum_bytes, need);
             if (rc != RT_OK) return rc;
         }
-        a.partials = ctx->d_partials;
-        RT_HIP(ctx, rtiow::launch_path(a, prm->kernel, ctx->num_cus, stream));
+        a.accum = ctx->d_accum;
+        RT_HIP(ctx, rtiow::launch_path(a, prm->kernel, prm->chunk_spp, ctx->num_cus, stream));
     }
     RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream));
     RT_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(rtiow::Counters),
@@ -276,7 +286,8 @@ int rtRender(RtContext* ctx, const RtCamera* cam, const RtParams* params, void* 
     if (ctx->n_spheres == 0) return fail(ctx, RT_ERR_STATE, "rtRender: PATH mode needs rtSetScene first");
     if (params->width < 2 || params->height < 2)
         return fail(ctx, RT_ERR_INVALID, "rtRender: PATH mode needs width,height >= 2");
-    if (params->spp == 0) return fail(ctx, RT_ERR_INVALID, "rtRender: spp must be >= 1");
+    if (params->spp == 0 || params->spp > 65536)
+        return fail(ctx, RT_ERR_INVALID, "rtRender: spp must be 1..65536");
     if (params->quantiser > RT_QUANT_BOOK) return fail(ctx, RT_ERR_INVALID, "rtRender: unknown quantiser");
     return render_common(ctx, false, nullptr, cam, params, dst, dst_pitch, dst_is_device, stream);
 }
@@ -318,18 +329,19 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
         ctx->stats.paths = ctx->h_counters->paths;
         ctx->stats.segments = ctx->h_counters->segments;
         ctx->stats.sphere_tests = ctx->stats.segments * ctx->stats.n_spheres;
+        for (int k = 0; k < 8; ++k) ctx->stats.debug[k] = ctx->h_counters->debug[k];
     }
     *out = ctx->stats;
     return RT_OK;
 }
 
 // Arithmetic conformance probe: runs op over host arrays on the GPU
-// (0 fma, 1 div, 2 sqrt, 3 mul, 4 add, 5 RNG draw).  Used by the parity tests to
+// (0 fma, 1 div, 2 sqrt, 3 mul, 4 add, 5 RNG draw, 6 fixed-point accumulate, 7 u64->float).  Used by the parity tests to
 // localise any CPU/GPU rounding difference to a single operation.
 int rtSelfTestArith(RtContext* ctx, uint32_t op, const float* a, const float* b, const float* c,
                     float* out, uint32_t n) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rtSelfTestArith: ctx is null");
-    if (!a || !b || !c || !out || n == 0 || op > 5)
+    if (!a || !b || !c || !out || n == 0 || op > 7)
         return fail(ctx, RT_ERR_INVALID, "rtSelfTestArith: bad arguments");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     float* d = nullptr;

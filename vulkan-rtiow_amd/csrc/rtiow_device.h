@@ -14,21 +14,31 @@ struct Counters {
     unsigned long long segments;
     unsigned long long queue_head;  // persistent kernel: next chunk id
     unsigned long long pad;
+    unsigned long long debug[8];    // diagnostic builds (-DRTIOW_DEBUG_COUNTERS) only
+};
+
+// Device-side shading record of one sphere (32 B), built by rtSetScene from RtSphere + RtMaterial.
+struct ShadeRec {
+    float albedo[3];
+    float param;     // fuzz (metal) or index of refraction (dielectric)
+    float inv_r;     // 1 / radius, rounded once on the host
+    uint32_t kind;   // RT_MAT_*
+    uint32_t pad[2];
 };
 
 struct PathArgs {
     const float4* spheres;       // n x {cx,cy,cz,radius} as uploaded (RtSphere)
-    const RtMaterial* materials; // n x 32 B
+    const ShadeRec* shade;       // n x 32 B
     uint32_t n;
     RtCamera cam;
     uint32_t width, height;      // full image
     uint32_t spp, max_depth, seed, quantiser;
-    uint32_t chunk_spp;          // normalised: 1..spp
+    float inv_wm1, inv_hm1;      // 1/(width-1), 1/(height-1), rounded once on the host
     uint32_t row_block, tile_rank, tile_count;
     uint32_t local_rows;         // rows this call renders
     uint32_t* dst;               // local_rows x dst_stride words
     uint32_t dst_stride;         // in 32-bit words
-    float4* partials;            // persistent kernel: local_pixels x chunks partial sums
+    unsigned long long* accum;   // persistent kernel: local_pixels x 4 fixed-point sums (r,g,b,pad)
     Counters* counters;
 };
 
@@ -44,12 +54,13 @@ struct ChArgs {
 enum : uint32_t {
     KERNEL_DEFAULT = 0,
     KERNEL_PIXEL = 1,      // one lane per pixel, spp loop inside (v1)
-    KERNEL_PERSISTENT = 2  // persistent waves + chunk queue + ballot refill (v2)
+    KERNEL_PERSISTENT = 2  // persistent waves + sample queue + ballot refill (v2)
 };
 
 hipError_t launch_ch(const ChArgs& a, hipStream_t stream);
-hipError_t launch_path(const PathArgs& a, uint32_t kernel, int num_cus, hipStream_t stream);
-size_t path_partials_bytes(const PathArgs& a, uint32_t kernel);
+hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, int num_cus,
+                       hipStream_t stream);
+size_t path_accum_bytes(const PathArgs& a, uint32_t kernel);
 hipError_t launch_arith(uint32_t op, const float* a, const float* b, const float* c, float* out,
                         uint32_t n, hipStream_t stream);
 

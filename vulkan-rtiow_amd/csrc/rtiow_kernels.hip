@@ -46,11 +46,20 @@ DI uint32_t quant_book(float x) {
 }
 DI uint32_t pack_rgb(uint32_t r, uint32_t g, uint32_t b) { return r | (g << 8) | (b << 16); }
 
-DI uint32_t resolve_pixel(f3 sum, uint32_t spp, uint32_t quantiser) {
-    const float scale = 1.0f / static_cast<float>(spp);
-    const float r = __builtin_sqrtf(scale * sum.x);
-    const float g = __builtin_sqrtf(scale * sum.y);
-    const float b = __builtin_sqrtf(scale * sum.z);
+// Multi-sample accumulate (a10): each sample's radiance goes to unsigned 32.32 fixed
+// point (clamp [0,32768], times 2^32 — exact — truncate) and pixels are INTEGER sums,
+// so the result does not depend on which lane added which sample, or in what order.
+DI unsigned long long to_fixed(float x) {
+    const float c = (x > 0.0f) ? (x < 32768.0f ? x : 32768.0f) : 0.0f;  // NaN -> 0
+    return static_cast<unsigned long long>(c * 4294967296.0f);
+}
+
+DI uint32_t resolve_pixel(unsigned long long sr, unsigned long long sg, unsigned long long sb,
+                          uint32_t spp, uint32_t quantiser) {
+    const float scale = 1.0f / (static_cast<float>(spp) * 4294967296.0f);
+    const float r = __builtin_sqrtf(scale * static_cast<float>(sr));
+    const float g = __builtin_sqrtf(scale * static_cast<float>(sg));
+    const float b = __builtin_sqrtf(scale * static_cast<float>(sb));
     if (quantiser == RT_QUANT_BOOK) return pack_rgb(quant_book(r), quant_book(g), quant_book(b));
     return pack_rgb(quant_unorm8(r), quant_unorm8(g), quant_unorm8(b));
 }
@@ -142,31 +151,52 @@ struct Path {
     DI Path() : rng(0u) {}
 };
 
-DI f3 random_in_unit_sphere(Pcg& rng) {
-    for (;;) {
-        f3 p;
-        p.x = rng.symmetric();
-        p.y = rng.symmetric();
-        p.z = rng.symmetric();
-        if (dot3(p, p) < 1.0f) return p;
-    }
+// Rejection-free sampling.  A rejection loop on a 64-wide SIMD runs for the MAXIMUM trip
+// count over the lanes, so the spec uses closed forms made of + - * sqrt and fma only.
+// sincos_2pi: quadrant from the top two bits of u, then two fma-only polynomials in
+// f = frac(4u) for sin(pi/2 f) and cos(pi/2 f) (max abs error 2e-7).
+DI void sincos_2pi(float u, float& c, float& s) {
+    constexpr float S0 = 0x1.921fb6p+0f, S1 = -0x1.4abbc4p-1f, S2 = 0x1.4668f0p-4f, S3 = -0x1.32533cp-8f,
+                    S4 = 0x1.3e15f6p-13f;
+    constexpr float C0 = 0x1.fffffep-1f, C1 = -0x1.3bd3a6p+0f, C2 = 0x1.03bd02p-2f, C3 = -0x1.54f5dcp-6f,
+                    C4 = 0x1.c1ecap-11f;
+    const float t = 4.0f * u;
+    const int q = static_cast<int>(t);
+    const float f = t - static_cast<float>(q);
+    const float f2 = f * f;
+    const float sp = f * fma_(f2, fma_(f2, fma_(f2, fma_(f2, S4, S3), S2), S1), S0);
+    const float cp = fma_(f2, fma_(f2, fma_(f2, fma_(f2, C4, C3), C2), C1), C0);
+    // q: 0 (c,s)=(cp,sp)  1 (-sp,cp)  2 (-cp,-sp)  3 (sp,-cp)
+    const float a = (q & 1) ? sp : cp;
+    const float b = (q & 1) ? cp : sp;
+    c = (q == 1 || q == 2) ? -a : a;
+    s = (q >= 2) ? -b : b;
+}
+
+DI f3 random_unit_vector(Pcg& rng) {
+    const float u1 = rng.uniform();
+    const float u2 = rng.uniform();
+    const float z = 1.0f - 2.0f * u1;
+    const float r = __builtin_sqrtf(fma_(-z, z, 1.0f));
+    float c, s;
+    sincos_2pi(u2, c, s);
+    return mk(r * c, r * s, z);
 }
 
 // one camera sample of pixel (i, j): SURVEY 9.4 / 9.5
 DI void camera_path(const PathArgs& a, uint32_t i, uint32_t j, uint32_t sample, Path& p) {
     const RtCamera& c = a.cam;
     p.rng = Pcg(a.seed, j * a.width + i, sample);
-    const float u = (static_cast<float>(i) + p.rng.uniform()) / static_cast<float>(a.width - 1);
-    const float v = (static_cast<float>(j) + p.rng.uniform()) / static_cast<float>(a.height - 1);
+    const float u = (static_cast<float>(i) + p.rng.uniform()) * a.inv_wm1;
+    const float v = (static_cast<float>(j) + p.rng.uniform()) * a.inv_hm1;
     f3 off = mk(0.0f, 0.0f, 0.0f);
-    if (c.lens_radius > 0.0f) {  // wave-uniform
-        float dx, dy;
-        for (;;) {  // random_in_unit_disk
-            dx = p.rng.symmetric();
-            dy = p.rng.symmetric();
-            if (fma_(dy, dy, dx * dx) < 1.0f) break;
-        }
-        const float rdx = c.lens_radius * dx, rdy = c.lens_radius * dy;
+    if (c.lens_radius > 0.0f) {  // wave-uniform; random_in_unit_disk: radius sqrt(u1), azimuth 2 pi u2
+        const float u1 = p.rng.uniform();
+        const float u2 = p.rng.uniform();
+        const float r = __builtin_sqrtf(u1);
+        float cs, sn;
+        sincos_2pi(u2, cs, sn);
+        const float rdx = c.lens_radius * (r * cs), rdy = c.lens_radius * (r * sn);
         off = mk(fma_(c.v[0], rdy, c.u[0] * rdx), fma_(c.v[1], rdy, c.u[1] * rdx),
                  fma_(c.v[2], rdy, c.u[2] * rdx));
     }
@@ -186,19 +216,19 @@ DI f3 sky_radiance(const Path& p) {  // raytrace06.comp:45-47, direction already
     return mk(p.att.x * c.x, p.att.y * c.y, p.att.z * c.z);
 }
 
-// Hit at distance s on sphere `idx`: scatter per material.
+// Hit at distance s on a sphere with centre `ctr` and shading record `m`: scatter per
+// material (metal fuzz as book v4: reflected + fuzz * random_unit_vector()).
 // Returns false when the path is absorbed (radiance 0).
-DI bool scatter(const PathArgs& a, int idx, float s, Path& p) {
-    const float4 sp = a.spheres[idx];  // cx, cy, cz, radius
-    const RtMaterial m = a.materials[idx];
+DI bool scatter(f3 ctr, const ShadeRec& m, float s, Path& p) {
     const f3 hit = mk(fma_(s, p.du.x, p.o.x), fma_(s, p.du.y, p.o.y), fma_(s, p.du.z, p.o.z));
-    const f3 outward = mk((hit.x - sp.x) / sp.w, (hit.y - sp.y) / sp.w, (hit.z - sp.z) / sp.w);
+    // inv_r = 1/radius (rounded once, on the host); negative radius flips the normal
+    const f3 outward = mk((hit.x - ctr.x) * m.inv_r, (hit.y - ctr.y) * m.inv_r, (hit.z - ctr.z) * m.inv_r);
     const float dn = dot3(p.du, outward);
     const bool front = dn < 0.0f;
     const f3 n = front ? outward : mk(-outward.x, -outward.y, -outward.z);
     f3 dir;
     if (m.kind == RT_MAT_LAMBERTIAN) {
-        const f3 rv = unit3(random_in_unit_sphere(p.rng));
+        const f3 rv = random_unit_vector(p.rng);
         dir = mk(n.x + rv.x, n.y + rv.y, n.z + rv.z);
         if (__builtin_fabsf(dir.x) < 1e-8f && __builtin_fabsf(dir.y) < 1e-8f &&
             __builtin_fabsf(dir.z) < 1e-8f)
@@ -208,15 +238,14 @@ DI bool scatter(const PathArgs& a, int idx, float s, Path& p) {
         const float k2 = 2.0f * dot3(p.du, n);
         const f3 refl = mk(fma_(-k2, n.x, p.du.x), fma_(-k2, n.y, p.du.y), fma_(-k2, n.z, p.du.z));
         dir = refl;
-        if (m.fuzz > 0.0f) {
-            const f3 rs = random_in_unit_sphere(p.rng);
-            dir = mk(fma_(m.fuzz, rs.x, refl.x), fma_(m.fuzz, rs.y, refl.y),
-                     fma_(m.fuzz, rs.z, refl.z));
+        if (m.param > 0.0f) {  // fuzz
+            const f3 rs = random_unit_vector(p.rng);
+            dir = mk(fma_(m.param, rs.x, refl.x), fma_(m.param, rs.y, refl.y), fma_(m.param, rs.z, refl.z));
         }
         if (!(dot3(dir, n) > 0.0f)) return false;
         p.att = mk(p.att.x * m.albedo[0], p.att.y * m.albedo[1], p.att.z * m.albedo[2]);
     } else {
-        const float ratio = front ? (1.0f / m.ior) : m.ior;
+        const float ratio = front ? (1.0f / m.param) : m.param;  // ior
         const float nd = -dot3(p.du, n);
         const float cosv = (nd < 1.0f) ? nd : 1.0f;
         const float sinv = __builtin_sqrtf(fma_(-cosv, cosv, 1.0f));
@@ -246,14 +275,17 @@ DI bool scatter(const PathArgs& a, int idx, float s, Path& p) {
 }
 
 // Stage the sphere list into LDS as {cx, cy, cz, r*r}: 16 B per sphere
-// (485 -> 7.6 KiB, 4096 -> 64 KiB; gfx950 has 160 KiB per CU).
-DI void stage_spheres(const PathArgs& a, float4* lds) {
-    for (uint32_t i = threadIdx.x; i < a.n; i += blockDim.x) {
-        float4 s = a.spheres[i];
-        s.w = s.w * s.w;
+// (485 -> 7.6 KiB, 4096 -> 64 KiB; gfx950 has 160 KiB per CU).  Padding entries
+// {0,0,0,-1} can never be hit: disc = hb^2 - |o|^2 - 1 < 0.
+DI void stage_spheres(const PathArgs& a, float4* lds, uint32_t n_pad) {
+    for (uint32_t i = threadIdx.x; i < n_pad; i += blockDim.x) {
+        float4 s = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+        if (i < a.n) {
+            s = a.spheres[i];
+            s.w = s.w * s.w;
+        }
         lds[i] = s;
     }
-    __syncthreads();
 }
 
 // Closest hit, straightforward form: all lanes walk the LDS list in lock-step
@@ -281,7 +313,7 @@ DI int closest_hit_simple(const float4* lds, uint32_t n, const Path& p, float& b
 }
 
 // ============================================================================
-// PATH v1: one lane per pixel
+// PATH v1: one lane per pixel (reference form; kept as a cross-check and ablation)
 // ============================================================================
 __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
     extern __shared__ float4 lds_spheres[];
@@ -290,7 +322,8 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
         blk_paths = 0;
         blk_segments = 0;
     }
-    stage_spheres(a, lds_spheres);
+    stage_spheres(a, lds_spheres, a.n);
+    __syncthreads();
 
     const uint32_t tiles_x = (a.width + 15u) / 16u;
     const uint32_t i = (blockIdx.x % tiles_x) * 16u + (threadIdx.x & 15u);
@@ -298,30 +331,27 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
     uint32_t n_paths = 0, n_segments = 0;
     if (i < a.width && lr < a.local_rows) {
         const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
-        f3 sum = mk(0.0f, 0.0f, 0.0f);
-        for (uint32_t s0 = 0; s0 < a.spp; s0 += a.chunk_spp) {
-            const uint32_t s1 = (s0 + a.chunk_spp < a.spp) ? s0 + a.chunk_spp : a.spp;
-            f3 part = mk(0.0f, 0.0f, 0.0f);
-            for (uint32_t s = s0; s < s1; ++s) {
-                Path p;
-                camera_path(a, i, j, s, p);
-                ++n_paths;
-                f3 rad = mk(0.0f, 0.0f, 0.0f);
-                for (uint32_t depth = 0; depth < a.max_depth; ++depth) {
-                    ++n_segments;
-                    float dist;
-                    const int idx = closest_hit_simple(lds_spheres, a.n, p, dist);
-                    if (idx < 0) {
-                        rad = sky_radiance(p);
-                        break;
-                    }
-                    if (!scatter(a, idx, dist, p)) break;
+        unsigned long long sr = 0ull, sg = 0ull, sb = 0ull;
+        for (uint32_t s = 0; s < a.spp; ++s) {
+            Path p;
+            camera_path(a, i, j, s, p);
+            ++n_paths;
+            for (uint32_t depth = 0; depth < a.max_depth; ++depth) {
+                ++n_segments;
+                float dist;
+                const int idx = closest_hit_simple(lds_spheres, a.n, p, dist);
+                if (idx < 0) {
+                    const f3 rad = sky_radiance(p);
+                    sr += to_fixed(rad.x);
+                    sg += to_fixed(rad.y);
+                    sb += to_fixed(rad.z);
+                    break;
                 }
-                part = mk(part.x + rad.x, part.y + rad.y, part.z + rad.z);
+                const float4 g = lds_spheres[idx];
+                if (!scatter(mk(g.x, g.y, g.z), a.shade[idx], dist, p)) break;
             }
-            sum = mk(sum.x + part.x, sum.y + part.y, sum.z + part.z);
         }
-        a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = resolve_pixel(sum, a.spp, a.quantiser);
+        a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = resolve_pixel(sr, sg, sb, a.spp, a.quantiser);
     }
     atomicAdd(&blk_paths, n_paths);
     atomicAdd(&blk_segments, n_segments);
@@ -333,44 +363,71 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 }
 
 // ============================================================================
-// PATH v2: persistent waves, chunk queue, ballot refill, candidate bitmasks
+// PATH v2: persistent waves, sample queue, ballot refill, candidate bitmasks
 // ============================================================================
 //
-// Work item = one chunk: chunk_spp consecutive samples of one pixel, summed
-// sequentially into one partial sum (the pixel is the sequential sum of its
-// partial sums, resolved by resolve_kernel: the order is part of the spec, so
-// the frame does not depend on which lane traced what).  Every lane owns R
-// path slots.  One loop iteration traces exactly one segment per live slot:
+// Work item = one camera sample; the queue is the flat index space
+// [0, pixels*spp) of this launch, handed out in short consecutive runs.  Every
+// lane owns kSlots path slots.  One loop iteration traces exactly one segment
+// per live slot:
 //
-//   refill   slots whose path ended start the next sample of their chunk; slots
-//            whose chunk is finished store its partial sum and pull a new chunk:
-//            __ballot of the needy lanes, ONE atomicAdd per wave on the queue
-//            head, ids handed out by mbcnt prefix — dead lanes are refilled
-//            immediately, so the sphere loop always runs with full waves.
+//   refill   two-level queue.  A wave keeps a pool of sample ids in SGPRs and
+//            refills it with ONE atomicAdd on the global queue head per ~2048
+//            samples (a single head word saturates near 90 dequeues/us, far
+//            below one dequeue per lane-run).  A slot that has started the last
+//            sample of its run takes its next run from the wave pool: __ballot
+//            of the asking lanes + mbcnt prefix, no memory traffic.  Dead lanes
+//            are refilled at once, so the sphere loop always runs with full
+//            waves.  Pool and run sizes shrink as the queue drains (guided
+//            self-scheduling): the tail of the frame is one path, not one pixel.
 //   trace    all lanes walk the LDS sphere list in lock-step (broadcast reads),
-//            branch-free: 11 VALU per ray-sphere test, the sign bit of the
-//            discriminant shifted into a per-lane candidate word by one
-//            v_alignbit.  Only candidates (a handful per ray) take the
-//            sqrt/root path, per lane, after each block of 32 spheres.
-//   shade    miss -> sky into the partial sum; hit -> scatter by material.
+//            branch-free: the sign bit of each discriminant is shifted into a
+//            per-lane candidate word by one v_alignbit.  Only candidates (about
+//            two per ray) take the sqrt/root path, per lane, after each block of
+//            32 spheres.
+//   shade    miss -> sky radiance into the slot's fixed-point accumulator;
+//            hit -> scatter by material (shading records staged in LDS too
+//            when the list is small enough).
 //
-// Order-independence: the closest hit is the minimum over spheres of each
-// sphere's first root in (t_min, inf), ties to the lowest index — exactly what
-// the oracle's sequential scan computes — so candidates may be examined in any
-// grouping.
+// Accumulators are 32.32 fixed point (to_fixed): integer sums are independent of
+// order, so a slot adds its samples in registers and merges them into the
+// per-pixel accumulator with 64-bit integer atomics whenever it moves to another
+// pixel.  resolve_kernel turns accumulators into RGBA8.
+//
+// The closest hit is order-independent too: it is the minimum over spheres of
+// each sphere's first root in (t_min, inf), ties to the lowest index — exactly
+// what the oracle's sequential scan computes.
 
-constexpr int kSlots = 2;          // path slots per lane
-constexpr uint32_t kBlockSph = 32; // spheres per candidate word
+constexpr int kSlots = 2;           // path slots per lane
+constexpr uint32_t kBlockSph = 32;  // spheres per candidate word
+constexpr uint32_t kAccStride = 4;  // u64 words per pixel accumulator (r, g, b, pad)
 
 struct Slot {
     Path p;
-    f3 part;               // partial sum of the current chunk
-    uint32_t pix;          // local pixel index
-    uint32_t s, s_end;     // next sample, end of chunk
-    uint32_t chunk;        // chunk id (index into partials)
+    unsigned long long acc_r, acc_g, acc_b;  // fixed-point sums not yet merged
+    uint32_t acc_pix;                        // pixel they (and the live path) belong to
+    uint32_t id, id_end;                     // run of sample ids still to start
+    uint32_t i, lr, s;                       // column / local row / sample index of sample `id`
     uint32_t depth;
-    bool active, has_chunk;
+    bool active, dirty;
 };
+
+struct PersistArgs {
+    uint32_t n_pad;        // sphere list padded to a multiple of kBlockSph
+    uint32_t pix_begin;    // first local pixel of this pass
+    uint32_t total;        // samples in this pass (< 2^32)
+    uint32_t max_take;     // longest run a slot may take from its wave's pool
+    uint32_t total_waves;  // waves of the grid
+};
+
+DI void flush_slot(const PathArgs& a, Slot& q) {
+    unsigned long long* acc = a.accum + static_cast<size_t>(q.acc_pix) * kAccStride;
+    atomicAdd(acc + 0, q.acc_r);
+    atomicAdd(acc + 1, q.acc_g);
+    atomicAdd(acc + 2, q.acc_b);
+    q.acc_r = q.acc_g = q.acc_b = 0ull;
+    q.dirty = false;
+}
 
 DI void examine_candidate(const float4* lds, uint32_t j, uint32_t n, const Path& p, float& best,
                           int& best_i) {
@@ -392,9 +449,18 @@ DI void examine_candidate(const float4* lds, uint32_t j, uint32_t n, const Path&
     best_i = static_cast<int>(j);
 }
 
+#ifdef RTIOW_DEBUG_COUNTERS
+#define DBG_ADD(var, x) (var) += (x)
+#define DBG_STAMP() __builtin_readcyclecounter()
+#else
+#define DBG_ADD(var, x) ((void)0)
+#define DBG_STAMP() 0ull
+#endif
+
 template <int R>
 DI void trace_slots(const float4* lds, uint32_t n_pad, uint32_t n, Slot (&sl)[R], float (&best)[R],
-                    int (&best_i)[R]) {
+                    int (&best_i)[R], uint32_t& dbg_slow_trips, uint32_t& dbg_cands,
+                    unsigned long long& dbg_t_slow) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         best[r] = __builtin_inff();
@@ -418,104 +484,147 @@ DI void trace_slots(const float4* lds, uint32_t n_pad, uint32_t n, Slot (&sl)[R]
                 miss[r] = __builtin_amdgcn_alignbit(miss[r], __float_as_uint(disc), 31);
             }
         }
+        [[maybe_unused]] const unsigned long long ts0 = DBG_STAMP();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             uint32_t cand = sl[r].active ? ~miss[r] : 0u;
+            DBG_ADD(dbg_cands, __builtin_popcount(cand));
+#ifdef RTIOW_DEBUG_COUNTERS
+            {  // wave-level trip count of the loop below = max over lanes of popcount
+                uint32_t m = __builtin_popcount(cand);
+                for (int off = 32; off > 0; off >>= 1) {
+                    const uint32_t o = __shfl_xor(m, off);
+                    m = o > m ? o : m;
+                }
+                if ((threadIdx.x & 63u) == 0u) dbg_slow_trips += m;
+            }
+#endif
             while (cand) {
                 const uint32_t bit = static_cast<uint32_t>(__builtin_clz(cand));
                 cand &= ~(0x80000000u >> bit);
                 examine_candidate(lds, base + bit, n, sl[r].p, best[r], best_i[r]);
             }
         }
+        DBG_ADD(dbg_t_slow, DBG_STAMP() - ts0);
     }
 }
 
-__global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, uint32_t n_pad,
-                                                              uint32_t chunks_per_pixel,
-                                                              unsigned long long total_chunks) {
+DI uint32_t lane_rank(unsigned long long mask) {  // number of set bits of mask below this lane
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
+template <bool SHADE_LDS>
+__global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, PersistArgs g) {
     extern __shared__ float4 lds_spheres[];
-    for (uint32_t i = threadIdx.x; i < n_pad; i += blockDim.x) {
-        float4 s;
-        if (i < a.n) {
-            s = a.spheres[i];
-            s.w = s.w * s.w;
-        } else {
-            s = make_float4(0.0f, 0.0f, 0.0f, -1.0f);  // padding: disc = hb^2 - |o|^2 - 1 < 0
-        }
-        lds_spheres[i] = s;
+    float4* lds_shade = lds_spheres + g.n_pad;  // SHADE_LDS: 2 x float4 per sphere
+    stage_spheres(a, lds_spheres, g.n_pad);
+    if (SHADE_LDS) {
+        const float4* src = reinterpret_cast<const float4*>(a.shade);
+        for (uint32_t i = threadIdx.x; i < 2u * a.n; i += blockDim.x) lds_shade[i] = src[i];
     }
     __syncthreads();
 
     Slot sl[kSlots];
 #pragma unroll
     for (int r = 0; r < kSlots; ++r) {
-        sl[r].active = false;
-        sl[r].has_chunk = false;
-        sl[r].part = mk(0.0f, 0.0f, 0.0f);
-        sl[r].pix = sl[r].s = sl[r].s_end = sl[r].chunk = sl[r].depth = 0u;
+        sl[r].active = sl[r].dirty = false;
+        sl[r].acc_r = sl[r].acc_g = sl[r].acc_b = 0ull;
+        sl[r].acc_pix = sl[r].id = sl[r].id_end = sl[r].i = sl[r].lr = sl[r].s = sl[r].depth = 0u;
         sl[r].p.o = sl[r].p.du = sl[r].p.att = mk(0.0f, 0.0f, 0.0f);
     }
-    bool exhausted = false;  // wave-uniform: the queue has been drained
+    // wave-uniform queue state (SGPRs)
+    uint32_t pool_next = 0u, pool_end = 0u;  // this wave's pool of sample ids
+    uint32_t lane_take = 1u;                 // run length handed to a slot
+    uint32_t last_base = 0u;                 // global head seen by the last pool refill
+    bool exhausted = false;                  // the global queue has been drained
     uint32_t n_paths = 0, n_segments = 0;
+    [[maybe_unused]] uint32_t dbg_slow_trips = 0, dbg_cands = 0, dbg_iters = 0;
+    [[maybe_unused]] unsigned long long dbg_t_refill = 0, dbg_t_trace = 0, dbg_t_slow = 0, dbg_t_shade = 0;
+    [[maybe_unused]] const unsigned long long dbg_c0 = DBG_STAMP();
+#ifdef RTIOW_DEBUG_COUNTERS
+    const unsigned long long dbg_w0 = wall_clock64();
+#endif
 
     for (;;) {
+        [[maybe_unused]] const unsigned long long t0 = DBG_STAMP();
         // ---- refill ---------------------------------------------------------
+        bool any_active = false;
 #pragma unroll
         for (int r = 0; r < kSlots; ++r) {
             Slot& q = sl[r];
-            bool need = !q.active && (!q.has_chunk || q.s == q.s_end);
-            if (need && q.has_chunk) {
-                a.partials[q.chunk] = make_float4(q.part.x, q.part.y, q.part.z, 0.0f);
-                q.has_chunk = false;
-            }
-            if (!exhausted) {
-                const unsigned long long mask = __ballot(need);
-                if (mask != 0ull) {
-                    const uint32_t want = static_cast<uint32_t>(__popcll(mask));
-                    unsigned long long base = 0ull;
-                    if (__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
-                            __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u)) == 0u && need)
-                        base = atomicAdd(&a.counters->queue_head, static_cast<unsigned long long>(want));
-                    // broadcast from the first needy lane
-                    const int leader = __builtin_ctzll(mask);
-                    const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(base), leader);
-                    const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(base >> 32), leader);
-                    base = (static_cast<unsigned long long>(hi) << 32) | lo;
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
-                        static_cast<uint32_t>(mask >> 32),
-                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
-                    const unsigned long long id = base + rank;
-                    if (need && id < total_chunks) {
-                        q.chunk = static_cast<uint32_t>(id);
-                        q.pix = static_cast<uint32_t>(id / chunks_per_pixel);
-                        const uint32_t k = static_cast<uint32_t>(id % chunks_per_pixel);
-                        q.s = k * a.chunk_spp;
-                        q.s_end = (q.s + a.chunk_spp < a.spp) ? q.s + a.chunk_spp : a.spp;
-                        q.part = mk(0.0f, 0.0f, 0.0f);
-                        q.has_chunk = true;
+            // a slot with no sample left to start (its last path may still be in flight)
+            // takes its next run from the wave pool
+            const bool need = q.id == q.id_end;
+            const unsigned long long mask = __ballot(need);
+            if (mask != 0ull) {
+                if (pool_next == pool_end && !exhausted) {
+                    // pool refill: one atomic per wave per pool; guided size
+                    const uint32_t rem = g.total - (last_base < g.total ? last_base : g.total);
+                    uint32_t batch = rem / (g.total_waves * 4u);
+                    batch = batch < 128u ? 128u : (batch > 2048u ? 2048u : batch);
+                    unsigned long long got = 0ull;
+                    if ((threadIdx.x & 63u) == 0u)
+                        got = atomicAdd(&a.counters->queue_head, static_cast<unsigned long long>(batch));
+                    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(got));
+                    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(got >> 32));
+                    // the head exceeds `total` by at most one over-shoot per wave: saturate
+                    const uint32_t base = hi != 0u ? 0xFFFFFFFFu : lo;
+                    last_base = base;
+                    if (base < g.total) {
+                        pool_next = base;
+                        pool_end = (g.total - base > batch) ? base + batch : g.total;
+                        uint32_t take = batch / 256u;
+                        lane_take = take < 1u ? 1u : (take > g.max_take ? g.max_take : take);
                     }
-                    if (base + want >= total_chunks) exhausted = true;
+                    if (static_cast<unsigned long long>(base) + batch >= g.total) exhausted = true;
+                }
+                if (pool_next != pool_end) {
+                    const uint32_t first = pool_next + lane_rank(mask) * lane_take;
+                    if (need && first < pool_end) {
+                        q.id = first;
+                        q.id_end = (pool_end - first > lane_take) ? first + lane_take : pool_end;
+                        const uint32_t pix = g.pix_begin + q.id / a.spp;
+                        q.s = q.id % a.spp;
+                        q.lr = pix / a.width;
+                        q.i = pix % a.width;
+                    }
+                    const uint32_t want = static_cast<uint32_t>(__popcll(mask)) * lane_take;
+                    pool_next = (pool_end - pool_next > want) ? pool_next + want : pool_end;
                 }
             }
-            if (!q.active && q.has_chunk) {  // next sample of the chunk
-                const uint32_t lr = q.pix / a.width, i = q.pix % a.width;
-                const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
-                camera_path(a, i, j, q.s, q.p);
-                ++q.s;
+            // start the next sample of the run
+            if (!q.active && q.id != q.id_end) {
+                const uint32_t pix = q.lr * a.width + q.i;
+                if (q.dirty && q.acc_pix != pix) flush_slot(a, q);
+                q.acc_pix = pix;
+                const uint32_t j = tile_global_row(q.lr, a.row_block, a.tile_rank, a.tile_count);
+                camera_path(a, q.i, j, q.s, q.p);
+                ++q.id;
+                if (++q.s == a.spp) {
+                    q.s = 0u;
+                    if (++q.i == a.width) {
+                        q.i = 0u;
+                        ++q.lr;
+                    }
+                }
                 q.depth = 0u;
                 q.active = true;
                 ++n_paths;
             }
+            any_active = any_active || q.active;
         }
-        bool any_active = false;
-#pragma unroll
-        for (int r = 0; r < kSlots; ++r) any_active = any_active || sl[r].active;
-        if (__ballot(any_active) == 0ull) break;  // queue drained and every path finished
+        // no live path anywhere in the wave: every slot asked and got nothing, i.e. the pool
+        // is empty and the global queue is drained
+        if (__ballot(any_active) == 0ull) break;
+        [[maybe_unused]] const unsigned long long t1 = DBG_STAMP();
 
         // ---- trace ----------------------------------------------------------
         float best[kSlots];
         int best_i[kSlots];
-        trace_slots<kSlots>(lds_spheres, n_pad, a.n, sl, best, best_i);
+        trace_slots<kSlots>(lds_spheres, g.n_pad, a.n, sl, best, best_i, dbg_slow_trips, dbg_cands, dbg_t_slow);
+        DBG_ADD(dbg_iters, (threadIdx.x & 63u) == 0u ? 1u : 0u);
+        [[maybe_unused]] const unsigned long long t2 = DBG_STAMP();
 
         // ---- shade ----------------------------------------------------------
 #pragma unroll
@@ -525,15 +634,35 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, uint3
             ++n_segments;
             if (best_i[r] < 0) {
                 const f3 rad = sky_radiance(q.p);
-                q.part = mk(q.part.x + rad.x, q.part.y + rad.y, q.part.z + rad.z);
+                q.acc_r += to_fixed(rad.x);
+                q.acc_g += to_fixed(rad.y);
+                q.acc_b += to_fixed(rad.z);
+                q.dirty = true;
                 q.active = false;
-            } else if (!scatter(a, best_i[r], best[r], q.p)) {
-                q.active = false;  // absorbed: radiance 0
-            } else if (++q.depth >= a.max_depth) {
-                q.active = false;  // depth exhausted: radiance 0
+            } else {
+                const float4 geo = lds_spheres[best_i[r]];
+                ShadeRec m;
+                if (SHADE_LDS) {
+                    const float4 m0 = lds_shade[2 * best_i[r]], m1 = lds_shade[2 * best_i[r] + 1];
+                    m.albedo[0] = m0.x; m.albedo[1] = m0.y; m.albedo[2] = m0.z; m.param = m0.w;
+                    m.inv_r = m1.x; m.kind = __float_as_uint(m1.y);
+                } else {
+                    m = a.shade[best_i[r]];
+                }
+                if (!scatter(mk(geo.x, geo.y, geo.z), m, best[r], q.p)) {
+                    q.active = false;  // absorbed: radiance 0
+                } else if (++q.depth >= a.max_depth) {
+                    q.active = false;  // depth exhausted: radiance 0
+                }
             }
         }
+        DBG_ADD(dbg_t_refill, t1 - t0);
+        DBG_ADD(dbg_t_trace, t2 - t1);
+        DBG_ADD(dbg_t_shade, DBG_STAMP() - t2);
     }
+#pragma unroll
+    for (int r = 0; r < kSlots; ++r)
+        if (sl[r].dirty) flush_slot(a, sl[r]);
 
     // one counter update per wave
     for (int off = 32; off > 0; off >>= 1) {
@@ -544,20 +673,31 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, uint3
         atomicAdd(&a.counters->paths, static_cast<unsigned long long>(n_paths));
         atomicAdd(&a.counters->segments, static_cast<unsigned long long>(n_segments));
     }
+#ifdef RTIOW_DEBUG_COUNTERS
+    // debug[0] wave-level slow-loop trips, [1] lane-level candidates, [2] wave iterations
+    atomicAdd(&a.counters->debug[0], static_cast<unsigned long long>(dbg_slow_trips));
+    atomicAdd(&a.counters->debug[1], static_cast<unsigned long long>(dbg_cands));
+    atomicAdd(&a.counters->debug[2], static_cast<unsigned long long>(dbg_iters));
+    if ((threadIdx.x & 63u) == 0u) {  // per-wave cycle shares: [3] refill [4] trace (incl. slow) [5] slow [6] shade
+        atomicAdd(&a.counters->debug[3], dbg_t_refill);
+        atomicAdd(&a.counters->debug[4], dbg_t_trace);
+        atomicAdd(&a.counters->debug[5], dbg_t_slow);
+        atomicAdd(&a.counters->debug[6], dbg_t_shade);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {  // clock = shader cycles per 100 MHz tick
+            const unsigned long long dc = DBG_STAMP() - dbg_c0, dw = wall_clock64() - dbg_w0;
+            a.counters->debug[7] = dw ? dc * 100ull / dw : 0ull;  // MHz
+        }
+    }
+#endif
 }
 
-// partial sums -> RGBA8, one lane per pixel (coalesced 4-byte stores: 256 B per wave)
-__global__ __launch_bounds__(256) void resolve_kernel(PathArgs a, uint32_t chunks_per_pixel) {
+// accumulators -> RGBA8, one lane per pixel (coalesced 4-byte stores: 256 B per wave)
+__global__ __launch_bounds__(256) void resolve_kernel(PathArgs a) {
     const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
     if (lp >= a.local_rows * a.width) return;
-    f3 sum = mk(0.0f, 0.0f, 0.0f);
-    const float4* part = a.partials + static_cast<size_t>(lp) * chunks_per_pixel;
-    for (uint32_t k = 0; k < chunks_per_pixel; ++k) {
-        const float4 v = part[k];
-        sum = mk(sum.x + v.x, sum.y + v.y, sum.z + v.z);
-    }
+    const unsigned long long* acc = a.accum + static_cast<size_t>(lp) * kAccStride;
     const uint32_t lr = lp / a.width, i = lp % a.width;
-    a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = resolve_pixel(sum, a.spp, a.quantiser);
+    a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = resolve_pixel(acc[0], acc[1], acc[2], a.spp, a.quantiser);
 }
 
 // ============================================================================
@@ -579,6 +719,11 @@ __global__ void arith_kernel(uint32_t op, const float* a, const float* b, const 
             for (int k = 0; k < 4; ++k) r = rng.uniform();
             break;
         }
+        case 6: r = static_cast<float>(to_fixed(a[i]) + to_fixed(b[i])); break;
+        case 7:
+            r = static_cast<float>((static_cast<unsigned long long>(__float_as_uint(a[i])) << 32) |
+                                   __float_as_uint(b[i]));
+            break;
         default: break;
     }
     out[i] = r;
@@ -592,16 +737,15 @@ hipError_t launch_ch(const ChArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-static uint32_t chunks_per_pixel(const PathArgs& a) { return (a.spp + a.chunk_spp - 1u) / a.chunk_spp; }
-
 static bool use_persistent(uint32_t kernel) { return kernel != KERNEL_PIXEL; }
 
-size_t path_partials_bytes(const PathArgs& a, uint32_t kernel) {
+size_t path_accum_bytes(const PathArgs& a, uint32_t kernel) {
     if (!use_persistent(kernel)) return 0;
-    return static_cast<size_t>(a.local_rows) * a.width * chunks_per_pixel(a) * sizeof(float4);
+    return static_cast<size_t>(a.local_rows) * a.width * kAccStride * sizeof(unsigned long long);
 }
 
-hipError_t launch_path(const PathArgs& a, uint32_t kernel, int num_cus, hipStream_t stream) {
+hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, int num_cus,
+                       hipStream_t stream) {
     if (!use_persistent(kernel)) {
         const uint32_t tiles = ((a.width + 15u) / 16u) * ((a.local_rows + 15u) / 16u);
         const size_t lds = static_cast<size_t>(a.n) * sizeof(float4);
@@ -613,31 +757,51 @@ hipError_t launch_path(const PathArgs& a, uint32_t kernel, int num_cus, hipStrea
         hipLaunchKernelGGL(path_pixel_kernel, dim3(tiles), dim3(256), lds, stream, a);
         return hipGetLastError();
     }
-    const uint32_t n_pad = (a.n + kBlockSph - 1u) / kBlockSph * kBlockSph;
-    const size_t lds = static_cast<size_t>(n_pad) * sizeof(float4);
-    // one LDS copy of the list per workgroup: small lists -> 256-thread groups (8 per CU);
-    // large lists -> 1024-thread groups so 16 waves share one copy
-    const uint32_t threads = lds <= 16u * 1024u ? 256u : 1024u;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(path_persistent_kernel),
+    PersistArgs g{};
+    g.n_pad = (a.n + kBlockSph - 1u) / kBlockSph * kBlockSph;
+    g.max_take = max_take == 0u ? 8u : (max_take > 4096u ? 4096u : max_take);
+    // LDS per workgroup: the padded sphere list (16 B each) and, while the total stays small
+    // enough for four 256-thread groups per CU, the shading records too (32 B each)
+    const size_t lds_geo = static_cast<size_t>(g.n_pad) * sizeof(float4);
+    const bool shade_lds = lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 32u * 1024u;
+    const size_t lds = lds_geo + (shade_lds ? static_cast<size_t>(a.n) * sizeof(ShadeRec) : 0u);
+    // small lists -> 256-thread groups; large lists -> 1024-thread groups so 16 waves share one copy
+    const uint32_t threads = lds <= 32u * 1024u ? 256u : 1024u;
+    auto kernel_fn = shade_lds ? path_persistent_kernel<true> : path_persistent_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return e;
     int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, path_persistent_kernel, static_cast<int>(threads), lds);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel_fn, static_cast<int>(threads), lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
-    const uint32_t cpp = chunks_per_pixel(a);
-    const unsigned long long total = static_cast<unsigned long long>(a.local_rows) * a.width * cpp;
-    // persistent grid: fill the chip once; never more lanes than work items
-    unsigned long long want_blocks = (total + threads * kSlots - 1) / (threads * kSlots);
-    unsigned long long grid = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256) * per_cu;
-    if (grid > want_blocks) grid = want_blocks;
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(path_persistent_kernel, dim3(static_cast<uint32_t>(grid)), dim3(threads), lds, stream, a,
-                       n_pad, cpp, total);
-    e = hipGetLastError();
+    e = hipMemsetAsync(a.accum, 0, path_accum_bytes(a, kernel), stream);
     if (e != hipSuccess) return e;
+
+    // a pass covers whole rows and fewer than 2^32 samples (32-bit sample ids)
+    const unsigned long long per_row = static_cast<unsigned long long>(a.width) * a.spp;
+    uint32_t rows_per_pass = static_cast<uint32_t>(0xFFFFFFF0ull / per_row);
+    if (rows_per_pass < 1u) return hipErrorInvalidValue;  // one row >= 2^32 samples
+    for (uint32_t row0 = 0; row0 < a.local_rows; row0 += rows_per_pass) {
+        const uint32_t rows = (a.local_rows - row0 < rows_per_pass) ? a.local_rows - row0 : rows_per_pass;
+        g.pix_begin = row0 * a.width;
+        g.total = static_cast<uint32_t>(per_row * rows);
+        // persistent grid: fill the chip once; never more slots than samples
+        unsigned long long grid = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256) * per_cu;
+        const unsigned long long want_blocks = (static_cast<unsigned long long>(g.total) + threads * kSlots - 1) / (threads * kSlots);
+        if (grid > want_blocks) grid = want_blocks;
+        if (grid < 1) grid = 1;
+        g.total_waves = static_cast<uint32_t>(grid) * (threads / 64u);
+        if (row0 != 0) {  // the queue head restarts for every pass
+            e = hipMemsetAsync(&a.counters->queue_head, 0, sizeof(unsigned long long), stream);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kernel_fn, dim3(static_cast<uint32_t>(grid)), dim3(threads), lds, stream, a, g);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     const uint32_t px = a.local_rows * a.width;
-    hipLaunchKernelGGL(resolve_kernel, dim3((px + 255u) / 256u), dim3(256), 0, stream, a, cpp);
+    hipLaunchKernelGGL(resolve_kernel, dim3((px + 255u) / 256u), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
