@@ -192,8 +192,8 @@ def main():
         achieved = flops / (kernel_ms * 1e-3) / 1e12
         fb_bytes = st.bytes_written
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if world == 1 and os.path.exists(tpath):
+        tpath = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "traffic_r*.json")) or [""])[-1]
+        if world == 1 and tpath and os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("workload") == args.workload:
                 traffic = tj.get("hbm_bytes_per_launch")

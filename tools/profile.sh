@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence bench.py's numbers are checked against (run on the GPU box):
+#   1. --kernel-trace --stats        per-kernel durations of the exact bench command
+#   2. --pmc FETCH_SIZE / WRITE_SIZE HBM traffic of each kernel (separate passes: TCC slots)
+#   3. --pmc SQ_*                    VALU / LDS / wait mix of the path kernel
+# Raw output goes to gpurun_out/prof_<tag>_*/ ; tools/profile_summary.py condenses it into profiles/.
+set -e
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+export TMPDIR=/tmp
+cd /tmp
+BENCH="python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_stats -- $BENCH > $O/prof_${TAG}_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_${TAG}_fetch -- $BENCH > $O/prof_${TAG}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_${TAG}_write -- $BENCH > $O/prof_${TAG}_write.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY \
+    --output-format csv -d $O/prof_${TAG}_sq -- $BENCH > $O/prof_${TAG}_sq.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE \
+    --output-format csv -d $O/prof_${TAG}_lds -- $BENCH > $O/prof_${TAG}_lds.log 2>&1 || true
+cd $R && python3 tools/profile_summary.py $TAG

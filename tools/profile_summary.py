@@ -1,0 +1,61 @@
+"""Condenses gpurun_out/prof_<tag>_* (rocprofv3 csv) into profiles/<tag>_kernel_stats.csv,
+profiles/<tag>_pmc.json and profiles/traffic_<tag>.json (read back by bench.py as roofline.traffic)."""
+import collections, csv, glob, json, os, re, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "gpurun_out")
+prof = os.path.join(root, "profiles")
+os.makedirs(prof, exist_ok=True)
+
+
+def one(pattern):
+    hits = sorted(glob.glob(os.path.join(out, pattern), recursive=True), key=os.path.getmtime)
+    return hits[-1] if hits else None
+
+
+ks = one(f"prof_{tag}_stats/**/*_kernel_stats.csv")
+if ks:
+    shutil.copy(ks, os.path.join(prof, f"{tag}_kernel_stats.csv"))
+bench_line = None
+log = os.path.join(out, f"prof_{tag}_stats.log")
+if os.path.exists(log):
+    for line in open(log):
+        if line.startswith("{\"metric\""):
+            bench_line = json.loads(line)
+            open(os.path.join(prof, f"{tag}_bench_under_rocprof.json"), "w").write(line)
+
+pmc = {}
+for kind in ("fetch", "write", "sq", "lds"):
+    f = one(f"prof_{tag}_{kind}/**/*_counter_collection.csv")
+    if not f:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+        name = re.sub(r"^void ", "", name)
+        name = re.sub(r"[(<].*", "", name).split("::")[-1]
+        agg[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        if "path_persistent" in name:
+            pmc.setdefault("_dispatch", {"vgpr": r["VGPR_Count"], "sgpr": r["SGPR_Count"], "lds": r["LDS_Block_Size"],
+                                         "scratch": r["Scratch_Size"], "grid": r["Grid_Size"], "wg": r["Workgroup_Size"]})
+    for (name, ctr), vals in agg.items():
+        pmc.setdefault(name, {})[ctr] = {"mean_per_launch": sum(vals) / len(vals), "launches": len(vals)}
+
+traffic = None
+pk = next((k for k in pmc if k.startswith("path_persistent")), None)
+rk = next((k for k in pmc if k.startswith("resolve")), None)
+if pk and "FETCH_SIZE" in pmc[pk] and "WRITE_SIZE" in pmc[pk]:
+    # MI355X_MICROARCH.md "HBM": counters are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B,
+    # so a wide streaming read is doubled; WRITE_SIZE is exact.
+    def bytes_of(k):
+        return (2.0 * pmc[k]["FETCH_SIZE"]["mean_per_launch"] + pmc[k]["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+    traffic = {"workload": (bench_line or {}).get("config", {}).get("workload", "cover_1200x800_100spp"),
+               "kernel": pk, "hbm_bytes_per_launch": bytes_of(pk),
+               "fetch_kib_raw": pmc[pk]["FETCH_SIZE"]["mean_per_launch"], "write_kib_raw": pmc[pk]["WRITE_SIZE"]["mean_per_launch"],
+               "resolve_kernel_hbm_bytes_per_launch": bytes_of(rk) if rk and "FETCH_SIZE" in pmc[rk] else None,
+               "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reads half of a wide stream)"}
+    json.dump(traffic, open(os.path.join(prof, f"traffic_{tag}.json"), "w"), indent=1)
+json.dump(pmc, open(os.path.join(prof, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+print("kernel stats:", open(os.path.join(prof, f"{tag}_kernel_stats.csv")).read() if ks else "missing")
+print("traffic:", traffic)

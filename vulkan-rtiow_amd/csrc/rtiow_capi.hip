@@ -26,8 +26,6 @@ struct RtContext {
     rtiow::Counters* h_counters = nullptr;  // pinned
     uint32_t* d_frame = nullptr;            // staging framebuffer for host destinations
     size_t frame_bytes = 0;
-    unsigned long long* d_accum = nullptr;  // fixed-point pixel accumulators
-    size_t accum_bytes = 0;
     bool have_timing = false;
     hipStream_t last_stream = nullptr;
     RtStats stats{};
@@ -124,7 +122,6 @@ int rtDestroy(RtContext* ctx) {
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
-    if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -249,12 +246,6 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         a.dst = out;
         a.dst_stride = out_stride;
         a.counters = ctx->d_counters;
-        const size_t need = rtiow::path_accum_bytes(a, prm->kernel);
-        if (need) {
-            int rc = ensure_bytes(ctx, reinterpret_cast<void**>(&ctx->d_accum), &ctx->accum_bytes, need);
-            if (rc != RT_OK) return rc;
-        }
-        a.accum = ctx->d_accum;
         RT_HIP(ctx, rtiow::launch_path(a, prm->kernel, prm->chunk_spp, ctx->num_cus, stream));
     }
     RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream));

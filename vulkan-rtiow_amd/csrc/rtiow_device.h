@@ -12,7 +12,8 @@ namespace rtiow {
 struct Counters {
     unsigned long long paths;
     unsigned long long segments;
-    unsigned long long queue_head;  // persistent kernel: next chunk id
+    unsigned int queue_head_pix;    // persistent kernel: next pixel of the global pool queue
+    unsigned int pad32;
     unsigned long long pad;
     unsigned long long debug[8];    // diagnostic builds (-DRTIOW_DEBUG_COUNTERS) only
 };
@@ -38,7 +39,6 @@ struct PathArgs {
     uint32_t local_rows;         // rows this call renders
     uint32_t* dst;               // local_rows x dst_stride words
     uint32_t dst_stride;         // in 32-bit words
-    unsigned long long* accum;   // persistent kernel: local_pixels x 4 fixed-point sums (r,g,b,pad)
     Counters* counters;
 };
 
@@ -60,7 +60,6 @@ enum : uint32_t {
 hipError_t launch_ch(const ChArgs& a, hipStream_t stream);
 hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, int num_cus,
                        hipStream_t stream);
-size_t path_accum_bytes(const PathArgs& a, uint32_t kernel);
 hipError_t launch_arith(uint32_t op, const float* a, const float* b, const float* c, float* out,
                         uint32_t n, hipStream_t stream);
 

@@ -363,71 +363,70 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 }
 
 // ============================================================================
-// PATH v2: persistent waves, sample queue, ballot refill, candidate bitmasks
+// PATH v2: persistent waves, pixel-pool queue, ballot refill, candidate bitmasks
 // ============================================================================
 //
-// Work item = one camera sample; the queue is the flat index space
-// [0, pixels*spp) of this launch, handed out in short consecutive runs.  Every
-// lane owns kSlots path slots.  One loop iteration traces exactly one segment
-// per live slot:
+// Every lane owns kSlots path slots; one loop iteration traces exactly one
+// segment per live slot.
 //
-//   refill   two-level queue.  A wave keeps a pool of sample ids in SGPRs and
-//            refills it with ONE atomicAdd on the global queue head per ~2048
-//            samples (a single head word saturates near 90 dequeues/us, far
-//            below one dequeue per lane-run).  A slot that has started the last
-//            sample of its run takes its next run from the wave pool: __ballot
-//            of the asking lanes + mbcnt prefix, no memory traffic.  Dead lanes
-//            are refilled at once, so the sphere loop always runs with full
-//            waves.  Pool and run sizes shrink as the queue drains (guided
-//            self-scheduling): the tail of the frame is one path, not one pixel.
+//   refill   two-level queue.  The global queue hands out POOLS of whole pixels
+//            (one atomicAdd per wave per ~2048 samples: a single head word
+//            saturates near 90 dequeues/us, far below one dequeue per lane).
+//            A pool belongs to ONE wave ("generation"): its per-pixel 32.32
+//            fixed-point accumulators live in that wave's LDS.  A slot that has
+//            started the last sample of its run takes the next run from the
+//            wave's current generation: __ballot of the asking lanes + mbcnt
+//            prefix, no memory traffic.  Dead lanes are refilled at once, so
+//            the sphere loop always runs with full waves; pool and run sizes
+//            shrink as the queue drains (guided self-scheduling), so the tail
+//            of the frame is a few paths, not a pixel.
 //   trace    all lanes walk the LDS sphere list in lock-step (broadcast reads),
 //            branch-free: the sign bit of each discriminant is shifted into a
 //            per-lane candidate word by one v_alignbit.  Only candidates (about
 //            two per ray) take the sqrt/root path, per lane, after each block of
 //            32 spheres.
-//   shade    miss -> sky radiance into the slot's fixed-point accumulator;
-//            hit -> scatter by material (shading records staged in LDS too
-//            when the list is small enough).
+//   shade    miss -> sky radiance, converted to fixed point and added to the
+//            pixel's LDS accumulator (ds_add_u64; integer sums do not depend on
+//            order); hit -> scatter by material (shading records in LDS too
+//            while the list is small).
+//   resolve  finished samples are counted per generation with ballots; when a
+//            generation is complete, lanes 0..npix-1 turn its accumulators into
+//            RGBA8 and store them: consecutive pixels, 4 B per lane, coalesced.
+//            This store is the only HBM traffic of the frame besides the
+//            one-time scene read: no accumulation buffer, no global atomics.
 //
-// Accumulators are 32.32 fixed point (to_fixed): integer sums are independent of
-// order, so a slot adds its samples in registers and merges them into the
-// per-pixel accumulator with 64-bit integer atomics whenever it moves to another
-// pixel.  resolve_kernel turns accumulators into RGBA8.
+// Up to kGens generations are open per wave, so a long path in an old pool
+// never blocks the hand-out of newer samples (a path is at most max_depth
+// iterations long; a pool lasts ~45).
 //
-// The closest hit is order-independent too: it is the minimum over spheres of
-// each sphere's first root in (t_min, inf), ties to the lowest index — exactly
-// what the oracle's sequential scan computes.
+// The closest hit is order-independent: it is the minimum over spheres of each
+// sphere's first root in (t_min, inf), ties to the lowest index — exactly what
+// the oracle's sequential scan computes.
 
 constexpr int kSlots = 2;           // path slots per lane
 constexpr uint32_t kBlockSph = 32;  // spheres per candidate word
-constexpr uint32_t kAccStride = 4;  // u64 words per pixel accumulator (r, g, b, pad)
+constexpr int kGens = 3;            // pools a wave may have open
+constexpr uint32_t kGenPix = 32;    // pixels per pool at most
+constexpr uint32_t kAccWords = 4;   // u64 words per pixel accumulator (r, g, b, pad)
+constexpr uint32_t kWaveAccBytes = kGens * kGenPix * kAccWords * 8u;  // 3 KiB of LDS per wave
 
 struct Slot {
     Path p;
-    unsigned long long acc_r, acc_g, acc_b;  // fixed-point sums not yet merged
-    uint32_t acc_pix;                        // pixel they (and the live path) belong to
-    uint32_t id, id_end;                     // run of sample ids still to start
-    uint32_t i, lr, s;                       // column / local row / sample index of sample `id`
+    uint32_t i, lr, s;  // column / local row / sample index of the NEXT sample to start
+    uint32_t rem;       // samples of the run still to start
+    uint32_t acc;       // accumulator of the next sample's pixel: gen * kGenPix + pixel-in-pool
+    uint32_t live_acc;  // accumulator of the path in flight
     uint32_t depth;
-    bool active, dirty;
+    bool active;
 };
 
 struct PersistArgs {
     uint32_t n_pad;        // sphere list padded to a multiple of kBlockSph
-    uint32_t pix_begin;    // first local pixel of this pass
-    uint32_t total;        // samples in this pass (< 2^32)
+    uint32_t total_pix;    // pixels of this tile (the global queue counts pixels)
     uint32_t max_take;     // longest run a slot may take from its wave's pool
     uint32_t total_waves;  // waves of the grid
+    uint32_t pool_pix;     // pixels per pool away from the tail: clamp(2048 / spp, 1, kGenPix)
 };
-
-DI void flush_slot(const PathArgs& a, Slot& q) {
-    unsigned long long* acc = a.accum + static_cast<size_t>(q.acc_pix) * kAccStride;
-    atomicAdd(acc + 0, q.acc_r);
-    atomicAdd(acc + 1, q.acc_g);
-    atomicAdd(acc + 2, q.acc_b);
-    q.acc_r = q.acc_g = q.acc_b = 0ull;
-    q.dirty = false;
-}
 
 DI void examine_candidate(const float4* lds, uint32_t j, uint32_t n, const Path& p, float& best,
                           int& best_i) {
@@ -514,30 +513,44 @@ DI uint32_t lane_rank(unsigned long long mask) {  // number of set bits of mask 
                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
+// wave-uniform 3-entry tables indexed by a wave-uniform value, without dynamic register indexing
+DI uint32_t sel3(const uint32_t (&t)[kGens], uint32_t k) { return k == 0u ? t[0] : (k == 1u ? t[1] : t[2]); }
+DI void set3(uint32_t (&t)[kGens], uint32_t k, uint32_t v) {
+    t[0] = k == 0u ? v : t[0];
+    t[1] = k == 1u ? v : t[1];
+    t[2] = k == 2u ? v : t[2];
+}
+
 template <bool SHADE_LDS>
 __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, PersistArgs g) {
     extern __shared__ float4 lds_spheres[];
     float4* lds_shade = lds_spheres + g.n_pad;  // SHADE_LDS: 2 x float4 per sphere
+    unsigned long long* lds_acc = reinterpret_cast<unsigned long long*>(lds_shade + (SHADE_LDS ? 2u * a.n : 0u)) +
+                                  (threadIdx.x / 64u) * (kWaveAccBytes / 8u);  // this wave's accumulators
     stage_spheres(a, lds_spheres, g.n_pad);
     if (SHADE_LDS) {
         const float4* src = reinterpret_cast<const float4*>(a.shade);
         for (uint32_t i = threadIdx.x; i < 2u * a.n; i += blockDim.x) lds_shade[i] = src[i];
     }
     __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
 
     Slot sl[kSlots];
 #pragma unroll
     for (int r = 0; r < kSlots; ++r) {
-        sl[r].active = sl[r].dirty = false;
-        sl[r].acc_r = sl[r].acc_g = sl[r].acc_b = 0ull;
-        sl[r].acc_pix = sl[r].id = sl[r].id_end = sl[r].i = sl[r].lr = sl[r].s = sl[r].depth = 0u;
+        sl[r].active = false;
+        sl[r].i = sl[r].lr = sl[r].s = sl[r].rem = sl[r].acc = sl[r].live_acc = sl[r].depth = 0u;
         sl[r].p.o = sl[r].p.du = sl[r].p.att = mk(0.0f, 0.0f, 0.0f);
     }
-    // wave-uniform queue state (SGPRs)
-    uint32_t pool_next = 0u, pool_end = 0u;  // this wave's pool of sample ids
-    uint32_t lane_take = 1u;                 // run length handed to a slot
-    uint32_t last_base = 0u;                 // global head seen by the last pool refill
-    bool exhausted = false;                  // the global queue has been drained
+    // wave-uniform queue state (SGPRs).  Generation k is a pool of gen_npix[k] whole pixels
+    // starting at local pixel gen_first[k]; gen_total[k] = samples in it (0 = slot free),
+    // gen_done[k] = samples finished.  Samples of generation `cur` are being handed out.
+    uint32_t gen_first[kGens] = {0u, 0u, 0u}, gen_npix[kGens] = {0u, 0u, 0u};
+    uint32_t gen_total[kGens] = {0u, 0u, 0u}, gen_done[kGens] = {0u, 0u, 0u};
+    uint32_t cur = 0u, cur_handed = 0u, cur_total = 0u;
+    uint32_t lane_take = 1u;
+    uint32_t last_head = 0u;  // global head (pixels) seen by the last pool fetch
+    bool exhausted = false;   // the global queue has been drained
     uint32_t n_paths = 0, n_segments = 0;
     [[maybe_unused]] uint32_t dbg_slow_trips = 0, dbg_cands = 0, dbg_iters = 0;
     [[maybe_unused]] unsigned long long dbg_t_refill = 0, dbg_t_trace = 0, dbg_t_slow = 0, dbg_t_shade = 0;
@@ -553,56 +566,61 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
 #pragma unroll
         for (int r = 0; r < kSlots; ++r) {
             Slot& q = sl[r];
-            // a slot with no sample left to start (its last path may still be in flight)
-            // takes its next run from the wave pool
-            const bool need = q.id == q.id_end;
+            const bool need = q.rem == 0u;  // no sample left to start (the last path may be in flight)
             const unsigned long long mask = __ballot(need);
             if (mask != 0ull) {
-                if (pool_next == pool_end && !exhausted) {
-                    // pool refill: one atomic per wave per pool; guided size
-                    const uint32_t rem = g.total - (last_base < g.total ? last_base : g.total);
-                    uint32_t batch = rem / (g.total_waves * 4u);
-                    batch = batch < 128u ? 128u : (batch > 2048u ? 2048u : batch);
-                    unsigned long long got = 0ull;
-                    if ((threadIdx.x & 63u) == 0u)
-                        got = atomicAdd(&a.counters->queue_head, static_cast<unsigned long long>(batch));
-                    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(got));
-                    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(got >> 32));
-                    // the head exceeds `total` by at most one over-shoot per wave: saturate
-                    const uint32_t base = hi != 0u ? 0xFFFFFFFFu : lo;
-                    last_base = base;
-                    if (base < g.total) {
-                        pool_next = base;
-                        pool_end = (g.total - base > batch) ? base + batch : g.total;
-                        uint32_t take = batch / 256u;
-                        lane_take = take < 1u ? 1u : (take > g.max_take ? g.max_take : take);
+                if (cur_handed == cur_total && !exhausted) {
+                    // open the next generation if its ring slot is free: one atomic per pool
+                    const uint32_t nxt = cur + 1u == kGens ? 0u : cur + 1u;
+                    if (sel3(gen_total, nxt) == 0u) {
+                        const uint32_t rem_pix = g.total_pix - (last_head < g.total_pix ? last_head : g.total_pix);
+                        uint32_t k = rem_pix / (g.total_waves * 4u);  // guided: pools shrink near the end
+                        k = k < 1u ? 1u : (k > g.pool_pix ? g.pool_pix : k);
+                        uint32_t got = 0u;
+                        if (lane == 0u) got = atomicAdd(&a.counters->queue_head_pix, k);
+                        got = __builtin_amdgcn_readfirstlane(got);
+                        last_head = got;
+                        if (got < g.total_pix) {
+                            const uint32_t npix = g.total_pix - got < k ? g.total_pix - got : k;
+                            cur = nxt;
+                            cur_handed = 0u;
+                            cur_total = npix * a.spp;
+                            set3(gen_first, nxt, got);
+                            set3(gen_npix, nxt, npix);
+                            set3(gen_total, nxt, cur_total);
+                            set3(gen_done, nxt, 0u);
+                            for (uint32_t t = lane; t < npix * kAccWords; t += 64u)
+                                lds_acc[nxt * kGenPix * kAccWords + t] = 0ull;
+                            const uint32_t take = cur_total / 256u;
+                            lane_take = take < 1u ? 1u : (take > g.max_take ? g.max_take : take);
+                        }
+                        if (got + k >= g.total_pix || got + k < got) exhausted = true;
                     }
-                    if (static_cast<unsigned long long>(base) + batch >= g.total) exhausted = true;
                 }
-                if (pool_next != pool_end) {
-                    const uint32_t first = pool_next + lane_rank(mask) * lane_take;
-                    if (need && first < pool_end) {
-                        q.id = first;
-                        q.id_end = (pool_end - first > lane_take) ? first + lane_take : pool_end;
-                        const uint32_t pix = g.pix_begin + q.id / a.spp;
-                        q.s = q.id % a.spp;
+                if (cur_handed != cur_total) {
+                    const uint32_t first = cur_handed + lane_rank(mask) * lane_take;
+                    if (need && first < cur_total) {
+                        q.rem = cur_total - first < lane_take ? cur_total - first : lane_take;
+                        const uint32_t po = first / a.spp;
+                        q.s = first - po * a.spp;
+                        q.acc = cur * kGenPix + po;
+                        const uint32_t pix = sel3(gen_first, cur) + po;
                         q.lr = pix / a.width;
-                        q.i = pix % a.width;
+                        q.i = pix - q.lr * a.width;
                     }
                     const uint32_t want = static_cast<uint32_t>(__popcll(mask)) * lane_take;
-                    pool_next = (pool_end - pool_next > want) ? pool_next + want : pool_end;
+                    cur_handed = cur_total - cur_handed > want ? cur_handed + want : cur_total;
                 }
             }
             // start the next sample of the run
-            if (!q.active && q.id != q.id_end) {
-                const uint32_t pix = q.lr * a.width + q.i;
-                if (q.dirty && q.acc_pix != pix) flush_slot(a, q);
-                q.acc_pix = pix;
+            if (!q.active && q.rem != 0u) {
                 const uint32_t j = tile_global_row(q.lr, a.row_block, a.tile_rank, a.tile_count);
                 camera_path(a, q.i, j, q.s, q.p);
-                ++q.id;
-                if (++q.s == a.spp) {
+                q.live_acc = q.acc;
+                --q.rem;
+                if (++q.s == a.spp) {  // the run continues in the next pixel of the pool
                     q.s = 0u;
+                    ++q.acc;
                     if (++q.i == a.width) {
                         q.i = 0u;
                         ++q.lr;
@@ -614,8 +632,8 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
             }
             any_active = any_active || q.active;
         }
-        // no live path anywhere in the wave: every slot asked and got nothing, i.e. the pool
-        // is empty and the global queue is drained
+        // No live path anywhere in the wave: every slot asked and got nothing, so the current
+        // pool is handed out, every opened pool is complete (and resolved), the queue drained.
         if (__ballot(any_active) == 0ull) break;
         [[maybe_unused]] const unsigned long long t1 = DBG_STAMP();
 
@@ -623,53 +641,73 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
         float best[kSlots];
         int best_i[kSlots];
         trace_slots<kSlots>(lds_spheres, g.n_pad, a.n, sl, best, best_i, dbg_slow_trips, dbg_cands, dbg_t_slow);
-        DBG_ADD(dbg_iters, (threadIdx.x & 63u) == 0u ? 1u : 0u);
+        DBG_ADD(dbg_iters, lane == 0u ? 1u : 0u);
         [[maybe_unused]] const unsigned long long t2 = DBG_STAMP();
 
         // ---- shade ----------------------------------------------------------
 #pragma unroll
         for (int r = 0; r < kSlots; ++r) {
             Slot& q = sl[r];
-            if (!q.active) continue;
-            ++n_segments;
-            if (best_i[r] < 0) {
-                const f3 rad = sky_radiance(q.p);
-                q.acc_r += to_fixed(rad.x);
-                q.acc_g += to_fixed(rad.y);
-                q.acc_b += to_fixed(rad.z);
-                q.dirty = true;
-                q.active = false;
-            } else {
-                const float4 geo = lds_spheres[best_i[r]];
-                ShadeRec m;
-                if (SHADE_LDS) {
-                    const float4 m0 = lds_shade[2 * best_i[r]], m1 = lds_shade[2 * best_i[r] + 1];
-                    m.albedo[0] = m0.x; m.albedo[1] = m0.y; m.albedo[2] = m0.z; m.param = m0.w;
-                    m.inv_r = m1.x; m.kind = __float_as_uint(m1.y);
+            bool finished = false;
+            if (q.active) {
+                ++n_segments;
+                if (best_i[r] < 0) {
+                    const f3 rad = sky_radiance(q.p);
+                    unsigned long long* acc = lds_acc + q.live_acc * kAccWords;
+                    atomicAdd(acc + 0, to_fixed(rad.x));  // ds_add_u64: order-independent integer sum
+                    atomicAdd(acc + 1, to_fixed(rad.y));
+                    atomicAdd(acc + 2, to_fixed(rad.z));
+                    finished = true;
                 } else {
-                    m = a.shade[best_i[r]];
+                    const float4 geo = lds_spheres[best_i[r]];
+                    ShadeRec m;
+                    if (SHADE_LDS) {
+                        const float4 m0 = lds_shade[2 * best_i[r]], m1 = lds_shade[2 * best_i[r] + 1];
+                        m.albedo[0] = m0.x; m.albedo[1] = m0.y; m.albedo[2] = m0.z; m.param = m0.w;
+                        m.inv_r = m1.x; m.kind = __float_as_uint(m1.y);
+                    } else {
+                        m = a.shade[best_i[r]];
+                    }
+                    if (!scatter(mk(geo.x, geo.y, geo.z), m, best[r], q.p)) {
+                        finished = true;  // absorbed: radiance 0
+                    } else if (++q.depth >= a.max_depth) {
+                        finished = true;  // depth exhausted: radiance 0
+                    }
                 }
-                if (!scatter(mk(geo.x, geo.y, geo.z), m, best[r], q.p)) {
-                    q.active = false;  // absorbed: radiance 0
-                } else if (++q.depth >= a.max_depth) {
-                    q.active = false;  // depth exhausted: radiance 0
+                if (finished) q.active = false;
+            }
+            // count finished samples per generation (wave-uniform)
+            const uint32_t fgen = q.live_acc / kGenPix;
+#pragma unroll
+            for (uint32_t k = 0; k < static_cast<uint32_t>(kGens); ++k)
+                gen_done[k] += static_cast<uint32_t>(__popcll(__ballot(finished && fgen == k)));
+        }
+        // ---- resolve complete generations: coalesced RGBA8 stores -----------------
+#pragma unroll
+        for (uint32_t k = 0; k < static_cast<uint32_t>(kGens); ++k) {
+            if (gen_total[k] != 0u && gen_done[k] == gen_total[k]) {
+                if (lane < gen_npix[k]) {
+                    const unsigned long long* acc = lds_acc + (k * kGenPix + lane) * kAccWords;
+                    const uint32_t pix = gen_first[k] + lane;
+                    const uint32_t lr = pix / a.width, i = pix - lr * a.width;
+                    a.dst[static_cast<size_t>(lr) * a.dst_stride + i] =
+                        resolve_pixel(acc[0], acc[1], acc[2], a.spp, a.quantiser);
                 }
+                gen_total[k] = 0u;  // ring slot free again
+                if (k == cur) cur_total = cur_handed = 0u;
             }
         }
         DBG_ADD(dbg_t_refill, t1 - t0);
         DBG_ADD(dbg_t_trace, t2 - t1);
         DBG_ADD(dbg_t_shade, DBG_STAMP() - t2);
     }
-#pragma unroll
-    for (int r = 0; r < kSlots; ++r)
-        if (sl[r].dirty) flush_slot(a, sl[r]);
 
     // one counter update per wave
     for (int off = 32; off > 0; off >>= 1) {
         n_paths += __shfl_down(n_paths, off);
         n_segments += __shfl_down(n_segments, off);
     }
-    if ((threadIdx.x & 63u) == 0u) {
+    if (lane == 0u) {
         atomicAdd(&a.counters->paths, static_cast<unsigned long long>(n_paths));
         atomicAdd(&a.counters->segments, static_cast<unsigned long long>(n_segments));
     }
@@ -678,7 +716,7 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
     atomicAdd(&a.counters->debug[0], static_cast<unsigned long long>(dbg_slow_trips));
     atomicAdd(&a.counters->debug[1], static_cast<unsigned long long>(dbg_cands));
     atomicAdd(&a.counters->debug[2], static_cast<unsigned long long>(dbg_iters));
-    if ((threadIdx.x & 63u) == 0u) {  // per-wave cycle shares: [3] refill [4] trace (incl. slow) [5] slow [6] shade
+    if (lane == 0u) {  // per-wave cycle shares: [3] refill [4] trace (incl. slow) [5] slow [6] shade
         atomicAdd(&a.counters->debug[3], dbg_t_refill);
         atomicAdd(&a.counters->debug[4], dbg_t_trace);
         atomicAdd(&a.counters->debug[5], dbg_t_slow);
@@ -689,15 +727,6 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
         }
     }
 #endif
-}
-
-// accumulators -> RGBA8, one lane per pixel (coalesced 4-byte stores: 256 B per wave)
-__global__ __launch_bounds__(256) void resolve_kernel(PathArgs a) {
-    const uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lp >= a.local_rows * a.width) return;
-    const unsigned long long* acc = a.accum + static_cast<size_t>(lp) * kAccStride;
-    const uint32_t lr = lp / a.width, i = lp % a.width;
-    a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = resolve_pixel(acc[0], acc[1], acc[2], a.spp, a.quantiser);
 }
 
 // ============================================================================
@@ -739,11 +768,6 @@ hipError_t launch_ch(const ChArgs& a, hipStream_t stream) {
 
 static bool use_persistent(uint32_t kernel) { return kernel != KERNEL_PIXEL; }
 
-size_t path_accum_bytes(const PathArgs& a, uint32_t kernel) {
-    if (!use_persistent(kernel)) return 0;
-    return static_cast<size_t>(a.local_rows) * a.width * kAccStride * sizeof(unsigned long long);
-}
-
 hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, int num_cus,
                        hipStream_t stream) {
     if (!use_persistent(kernel)) {
@@ -760,13 +784,17 @@ hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, in
     PersistArgs g{};
     g.n_pad = (a.n + kBlockSph - 1u) / kBlockSph * kBlockSph;
     g.max_take = max_take == 0u ? 8u : (max_take > 4096u ? 4096u : max_take);
-    // LDS per workgroup: the padded sphere list (16 B each) and, while the total stays small
-    // enough for four 256-thread groups per CU, the shading records too (32 B each)
+    g.total_pix = a.local_rows * a.width;
+    g.pool_pix = 2048u / a.spp;
+    g.pool_pix = g.pool_pix < 1u ? 1u : (g.pool_pix > kGenPix ? kGenPix : g.pool_pix);
+    // LDS per workgroup: the padded sphere list (16 B each); while the list is small, the
+    // shading records too (32 B each); and 3 KiB of pixel accumulators per wave.
     const size_t lds_geo = static_cast<size_t>(g.n_pad) * sizeof(float4);
-    const bool shade_lds = lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 32u * 1024u;
-    const size_t lds = lds_geo + (shade_lds ? static_cast<size_t>(a.n) * sizeof(ShadeRec) : 0u);
-    // small lists -> 256-thread groups; large lists -> 1024-thread groups so 16 waves share one copy
-    const uint32_t threads = lds <= 32u * 1024u ? 256u : 1024u;
+    const bool shade_lds = lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 24u * 1024u;
+    const size_t lds_scene = lds_geo + (shade_lds ? static_cast<size_t>(a.n) * sizeof(ShadeRec) : 0u);
+    // small scenes -> 256-thread groups; large ones -> 1024-thread groups so 16 waves share one copy
+    const uint32_t threads = lds_scene <= 24u * 1024u ? 256u : 1024u;
+    const size_t lds = lds_scene + static_cast<size_t>(threads / 64u) * kWaveAccBytes;
     auto kernel_fn = shade_lds ? path_persistent_kernel<true> : path_persistent_kernel<false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -775,33 +803,14 @@ hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, in
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel_fn, static_cast<int>(threads), lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
-    e = hipMemsetAsync(a.accum, 0, path_accum_bytes(a, kernel), stream);
-    if (e != hipSuccess) return e;
-
-    // a pass covers whole rows and fewer than 2^32 samples (32-bit sample ids)
-    const unsigned long long per_row = static_cast<unsigned long long>(a.width) * a.spp;
-    uint32_t rows_per_pass = static_cast<uint32_t>(0xFFFFFFF0ull / per_row);
-    if (rows_per_pass < 1u) return hipErrorInvalidValue;  // one row >= 2^32 samples
-    for (uint32_t row0 = 0; row0 < a.local_rows; row0 += rows_per_pass) {
-        const uint32_t rows = (a.local_rows - row0 < rows_per_pass) ? a.local_rows - row0 : rows_per_pass;
-        g.pix_begin = row0 * a.width;
-        g.total = static_cast<uint32_t>(per_row * rows);
-        // persistent grid: fill the chip once; never more slots than samples
-        unsigned long long grid = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256) * per_cu;
-        const unsigned long long want_blocks = (static_cast<unsigned long long>(g.total) + threads * kSlots - 1) / (threads * kSlots);
-        if (grid > want_blocks) grid = want_blocks;
-        if (grid < 1) grid = 1;
-        g.total_waves = static_cast<uint32_t>(grid) * (threads / 64u);
-        if (row0 != 0) {  // the queue head restarts for every pass
-            e = hipMemsetAsync(&a.counters->queue_head, 0, sizeof(unsigned long long), stream);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(kernel_fn, dim3(static_cast<uint32_t>(grid)), dim3(threads), lds, stream, a, g);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
-    const uint32_t px = a.local_rows * a.width;
-    hipLaunchKernelGGL(resolve_kernel, dim3((px + 255u) / 256u), dim3(256), 0, stream, a);
+    // persistent grid: fill the chip once; never more slots than samples
+    unsigned long long grid = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256) * per_cu;
+    const unsigned long long samples = static_cast<unsigned long long>(g.total_pix) * a.spp;
+    const unsigned long long want_blocks = (samples + threads * kSlots - 1) / (threads * kSlots);
+    if (grid > want_blocks) grid = want_blocks;
+    if (grid < 1) grid = 1;
+    g.total_waves = static_cast<uint32_t>(grid) * (threads / 64u);
+    hipLaunchKernelGGL(kernel_fn, dim3(static_cast<uint32_t>(grid)), dim3(threads), lds, stream, a, g);
     return hipGetLastError();
 }
 
