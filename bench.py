@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--row-block", type=int, default=4)
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
 
     import numpy as np
@@ -119,12 +119,20 @@ def main():
         raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # rehearsal knobs (not used by the driver): BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # BENCH_BACKEND=gloo replaces RCCL, so the N>1 code path can run on a one-GPU box
+    if os.environ.get("BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         D = __import__("importlib").import_module("vulkan-rtiow_amd.dist")
 
     scene, grid_half, w, h, spp, depth = WORKLOADS[args.workload]
@@ -172,7 +180,8 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
     st = ctx.stats()
 
-    t = torch.tensor([elapsed, kernel_ms, float(st.segments)], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, kernel_ms, float(st.segments)], dtype=torch.float64,
+                     device=dev if backend == "nccl" else "cpu")
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

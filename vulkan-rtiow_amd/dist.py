@@ -38,6 +38,10 @@ def gather_frame(local: torch.Tensor, height: int, row_block: int, rank: int, wo
     returns the assembled [height, width] frame there (None elsewhere)."""
     if world <= 1:
         return local
+    # RCCL moves device tensors; a gloo rehearsal (tests, or two ranks sharing one GPU) stages via host
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        frame = gather_frame(local.cpu(), height, row_block, rank, world, dst, group)
+        return frame.to(local.device) if frame is not None else None
     width = local.shape[1]
     pad_rows = max_tile_rows(height, row_block, world)
     send = local
