@@ -3,7 +3,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vulkan_rtiow_amd as V
 
-w, h, spp = 1200, 800, int(sys.argv[1]) if len(sys.argv) > 1 else 20
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+w = int(sys.argv[2]) if len(sys.argv) > 2 else 1200
+h = int(sys.argv[3]) if len(sys.argv) > 3 else 800
 sph, mat = V.make_cover_scene(1, 11)
 cam = V.make_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, w / h, 0.1, 10.0)
 with V.Context(0) as ctx:

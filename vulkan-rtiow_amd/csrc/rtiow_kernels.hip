@@ -363,23 +363,20 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 }
 
 // ============================================================================
-// PATH v2: persistent waves, pixel-pool queue, ballot refill, candidate bitmasks
+// PATH v2: persistent waves, per-pixel LDS accumulators, ballot refill, candidate bitmasks
 // ============================================================================
 //
 // Every lane owns kSlots path slots; one loop iteration traces exactly one
 // segment per live slot.
 //
-//   refill   two-level queue.  The global queue hands out POOLS of whole pixels
-//            (one atomicAdd per wave per ~2048 samples: a single head word
+//   refill   two-level queue.  The global queue hands out pools of consecutive
+//            pixels (one atomicAdd per wave per pool; a single head word
 //            saturates near 90 dequeues/us, far below one dequeue per lane).
-//            A pool belongs to ONE wave ("generation"): its per-pixel 32.32
-//            fixed-point accumulators live in that wave's LDS.  A slot that has
-//            started the last sample of its run takes the next run from the
-//            wave's current generation: __ballot of the asking lanes + mbcnt
-//            prefix, no memory traffic.  Dead lanes are refilled at once, so
-//            the sphere loop always runs with full waves; pool and run sizes
-//            shrink as the queue drains (guided self-scheduling), so the tail
-//            of the frame is a few paths, not a pixel.
+//            A wave walks its pool pixel by pixel, sample by sample: the idle
+//            slots of the wave are found with __ballot, ranked with mbcnt and
+//            given consecutive samples of the current pixel, no memory traffic.
+//            Dead lanes are refilled at once, so the sphere loop always runs
+//            with full waves; pools shrink to one pixel as the queue drains.
 //   trace    all lanes walk the LDS sphere list in lock-step (broadcast reads),
 //            branch-free: the sign bit of each discriminant is shifted into a
 //            per-lane candidate word by one v_alignbit.  Only candidates (about
@@ -389,15 +386,13 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 //            pixel's LDS accumulator (ds_add_u64; integer sums do not depend on
 //            order); hit -> scatter by material (shading records in LDS too
 //            while the list is small).
-//   resolve  finished samples are counted per generation with ballots; when a
-//            generation is complete, lanes 0..npix-1 turn its accumulators into
-//            RGBA8 and store them: consecutive pixels, 4 B per lane, coalesced.
-//            This store is the only HBM traffic of the frame besides the
-//            one-time scene read: no accumulation buffer, no global atomics.
-//
-// Up to kGens generations are open per wave, so a long path in an old pool
-// never blocks the hand-out of newer samples (a path is at most max_depth
-// iterations long; a pool lasts ~45).
+//   resolve  every pixel in flight owns one of the wave's 64 LDS accumulator
+//            entries {r, g, b, samples done}.  The lane whose sample completes
+//            the pixel (returning ds_add on the counter) converts it to RGBA8
+//            and stores it; pixels of a wave finish in pixel order, so the L2
+//            merges the 4-byte stores into full lines.  This store is the only
+//            HBM traffic of the frame besides the one-time scene read: no
+//            accumulation buffer, no global atomics, no resolve pass.
 //
 // The closest hit is order-independent: it is the minimum over spheres of each
 // sphere's first root in (t_min, inf), ties to the lowest index — exactly what
@@ -405,17 +400,14 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 
 constexpr int kSlots = 2;           // path slots per lane
 constexpr uint32_t kBlockSph = 32;  // spheres per candidate word
-constexpr int kGens = 3;            // pools a wave may have open
-constexpr uint32_t kGenPix = 32;    // pixels per pool at most
-constexpr uint32_t kAccWords = 4;   // u64 words per pixel accumulator (r, g, b, pad)
-constexpr uint32_t kWaveAccBytes = kGens * kGenPix * kAccWords * 8u;  // 3 KiB of LDS per wave
+constexpr uint32_t kAccEntries = 64;                 // pixels a wave may have in flight
+constexpr uint32_t kAccWords = 4;                    // u64 words per entry: r, g, b, samples done
+constexpr uint32_t kWaveAccBytes = kAccEntries * kAccWords * 8u;  // 2 KiB of LDS per wave
 
 struct Slot {
     Path p;
-    uint32_t i, lr, s;  // column / local row / sample index of the NEXT sample to start
-    uint32_t rem;       // samples of the run still to start
-    uint32_t acc;       // accumulator of the next sample's pixel: gen * kGenPix + pixel-in-pool
-    uint32_t live_acc;  // accumulator of the path in flight
+    uint32_t pix;    // local pixel of the path in flight
+    uint32_t entry;  // its accumulator entry
     uint32_t depth;
     bool active;
 };
@@ -423,9 +415,8 @@ struct Slot {
 struct PersistArgs {
     uint32_t n_pad;        // sphere list padded to a multiple of kBlockSph
     uint32_t total_pix;    // pixels of this tile (the global queue counts pixels)
-    uint32_t max_take;     // longest run a slot may take from its wave's pool
     uint32_t total_waves;  // waves of the grid
-    uint32_t pool_pix;     // pixels per pool away from the tail: clamp(2048 / spp, 1, kGenPix)
+    uint32_t pool_pix;     // pixels per pool away from the tail
 };
 
 DI void examine_candidate(const float4* lds, uint32_t j, uint32_t n, const Path& p, float& best,
@@ -513,20 +504,12 @@ DI uint32_t lane_rank(unsigned long long mask) {  // number of set bits of mask 
                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
-// wave-uniform 3-entry tables indexed by a wave-uniform value, without dynamic register indexing
-DI uint32_t sel3(const uint32_t (&t)[kGens], uint32_t k) { return k == 0u ? t[0] : (k == 1u ? t[1] : t[2]); }
-DI void set3(uint32_t (&t)[kGens], uint32_t k, uint32_t v) {
-    t[0] = k == 0u ? v : t[0];
-    t[1] = k == 1u ? v : t[1];
-    t[2] = k == 2u ? v : t[2];
-}
-
 template <bool SHADE_LDS>
 __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, PersistArgs g) {
     extern __shared__ float4 lds_spheres[];
     float4* lds_shade = lds_spheres + g.n_pad;  // SHADE_LDS: 2 x float4 per sphere
     unsigned long long* lds_acc = reinterpret_cast<unsigned long long*>(lds_shade + (SHADE_LDS ? 2u * a.n : 0u)) +
-                                  (threadIdx.x / 64u) * (kWaveAccBytes / 8u);  // this wave's accumulators
+                                  (threadIdx.x / 64u) * (kWaveAccBytes / 8u);  // this wave's accumulator entries
     stage_spheres(a, lds_spheres, g.n_pad);
     if (SHADE_LDS) {
         const float4* src = reinterpret_cast<const float4*>(a.shade);
@@ -539,18 +522,15 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
 #pragma unroll
     for (int r = 0; r < kSlots; ++r) {
         sl[r].active = false;
-        sl[r].i = sl[r].lr = sl[r].s = sl[r].rem = sl[r].acc = sl[r].live_acc = sl[r].depth = 0u;
+        sl[r].pix = sl[r].entry = sl[r].depth = 0u;
         sl[r].p.o = sl[r].p.du = sl[r].p.att = mk(0.0f, 0.0f, 0.0f);
     }
-    // wave-uniform queue state (SGPRs).  Generation k is a pool of gen_npix[k] whole pixels
-    // starting at local pixel gen_first[k]; gen_total[k] = samples in it (0 = slot free),
-    // gen_done[k] = samples finished.  Samples of generation `cur` are being handed out.
-    uint32_t gen_first[kGens] = {0u, 0u, 0u}, gen_npix[kGens] = {0u, 0u, 0u};
-    uint32_t gen_total[kGens] = {0u, 0u, 0u}, gen_done[kGens] = {0u, 0u, 0u};
-    uint32_t cur = 0u, cur_handed = 0u, cur_total = 0u;
-    uint32_t lane_take = 1u;
-    uint32_t last_head = 0u;  // global head (pixels) seen by the last pool fetch
-    bool exhausted = false;   // the global queue has been drained
+    // wave-uniform queue state (SGPRs)
+    uint32_t pool_next = 0u, pool_end = 0u;  // pixels of the wave's pool not yet begun
+    uint32_t cur_pix = 0u, cur_entry = 0u;   // pixel being handed out and its accumulator entry
+    uint32_t cur_s = a.spp;                  // its next sample; == spp: no pixel open
+    unsigned long long free_entries = ~0ull; // accumulator entries not in use
+    bool exhausted = false;                  // the global queue has been drained
     uint32_t n_paths = 0, n_segments = 0;
     [[maybe_unused]] uint32_t dbg_slow_trips = 0, dbg_cands = 0, dbg_iters = 0;
     [[maybe_unused]] unsigned long long dbg_t_refill = 0, dbg_t_trace = 0, dbg_t_slow = 0, dbg_t_shade = 0;
@@ -566,74 +546,63 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
 #pragma unroll
         for (int r = 0; r < kSlots; ++r) {
             Slot& q = sl[r];
-            const bool need = q.rem == 0u;  // no sample left to start (the last path may be in flight)
-            const unsigned long long mask = __ballot(need);
-            if (mask != 0ull) {
-                if (cur_handed == cur_total && !exhausted) {
-                    // open the next generation if its ring slot is free: one atomic per pool
-                    const uint32_t nxt = cur + 1u == kGens ? 0u : cur + 1u;
-                    if (sel3(gen_total, nxt) == 0u) {
-                        const uint32_t rem_pix = g.total_pix - (last_head < g.total_pix ? last_head : g.total_pix);
-                        uint32_t k = rem_pix / (g.total_waves * 4u);  // guided: pools shrink near the end
+            const unsigned long long mask = __ballot(!q.active);  // idle slots: one sample each
+            const uint32_t want = static_cast<uint32_t>(__popcll(mask));
+            const uint32_t rank = lane_rank(mask);
+            uint32_t served = 0u;  // wave-uniform: idle lanes already given a sample this round
+            uint32_t my_s = 0u;
+            bool got_sample = false;
+            while (served < want) {  // one trip per pixel touched (1-2 unless spp is tiny)
+                if (cur_s == a.spp) {  // open the next pixel of the pool
+                    if (pool_next == pool_end) {
+                        if (exhausted) break;
+                        // pool fetch: one atomic per wave per pool.  Guided size from the CURRENT
+                        // head (a stale one would let a wave grab a full pool of the last pixels).
+                        uint32_t head_now = 0u;
+                        if (lane == 0u)
+                            head_now = __hip_atomic_load(&a.counters->queue_head_pix, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+                        head_now = __builtin_amdgcn_readfirstlane(head_now);
+                        const uint32_t rem_pix = g.total_pix - (head_now < g.total_pix ? head_now : g.total_pix);
+                        uint32_t k = rem_pix / (g.total_waves * 2u);
                         k = k < 1u ? 1u : (k > g.pool_pix ? g.pool_pix : k);
                         uint32_t got = 0u;
                         if (lane == 0u) got = atomicAdd(&a.counters->queue_head_pix, k);
                         got = __builtin_amdgcn_readfirstlane(got);
-                        last_head = got;
-                        if (got < g.total_pix) {
-                            const uint32_t npix = g.total_pix - got < k ? g.total_pix - got : k;
-                            cur = nxt;
-                            cur_handed = 0u;
-                            cur_total = npix * a.spp;
-                            set3(gen_first, nxt, got);
-                            set3(gen_npix, nxt, npix);
-                            set3(gen_total, nxt, cur_total);
-                            set3(gen_done, nxt, 0u);
-                            for (uint32_t t = lane; t < npix * kAccWords; t += 64u)
-                                lds_acc[nxt * kGenPix * kAccWords + t] = 0ull;
-                            const uint32_t take = cur_total / 256u;
-                            lane_take = take < 1u ? 1u : (take > g.max_take ? g.max_take : take);
-                        }
                         if (got + k >= g.total_pix || got + k < got) exhausted = true;
+                        if (got >= g.total_pix) break;
+                        pool_next = got;
+                        pool_end = g.total_pix - got < k ? g.total_pix : got + k;
                     }
+                    if (free_entries == 0ull) break;  // 64 pixels in flight: wait for one to finish
+                    cur_entry = static_cast<uint32_t>(__builtin_ctzll(free_entries));
+                    free_entries &= free_entries - 1ull;
+                    cur_pix = pool_next++;
+                    cur_s = 0u;
+                    if (lane < kAccWords) lds_acc[cur_entry * kAccWords + lane] = 0ull;
                 }
-                if (cur_handed != cur_total) {
-                    const uint32_t first = cur_handed + lane_rank(mask) * lane_take;
-                    if (need && first < cur_total) {
-                        q.rem = cur_total - first < lane_take ? cur_total - first : lane_take;
-                        const uint32_t po = first / a.spp;
-                        q.s = first - po * a.spp;
-                        q.acc = cur * kGenPix + po;
-                        const uint32_t pix = sel3(gen_first, cur) + po;
-                        q.lr = pix / a.width;
-                        q.i = pix - q.lr * a.width;
-                    }
-                    const uint32_t want = static_cast<uint32_t>(__popcll(mask)) * lane_take;
-                    cur_handed = cur_total - cur_handed > want ? cur_handed + want : cur_total;
+                const uint32_t n = want - served < a.spp - cur_s ? want - served : a.spp - cur_s;
+                if (!q.active && rank >= served && rank < served + n) {
+                    q.pix = cur_pix;
+                    q.entry = cur_entry;
+                    my_s = cur_s + (rank - served);
+                    got_sample = true;
                 }
+                cur_s += n;
+                served += n;
             }
-            // start the next sample of the run
-            if (!q.active && q.rem != 0u) {
-                const uint32_t j = tile_global_row(q.lr, a.row_block, a.tile_rank, a.tile_count);
-                camera_path(a, q.i, j, q.s, q.p);
-                q.live_acc = q.acc;
-                --q.rem;
-                if (++q.s == a.spp) {  // the run continues in the next pixel of the pool
-                    q.s = 0u;
-                    ++q.acc;
-                    if (++q.i == a.width) {
-                        q.i = 0u;
-                        ++q.lr;
-                    }
-                }
+            if (got_sample) {  // start the sample
+                const uint32_t lr = q.pix / a.width, i = q.pix - lr * a.width;
+                const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
+                camera_path(a, i, j, my_s, q.p);
                 q.depth = 0u;
                 q.active = true;
                 ++n_paths;
             }
             any_active = any_active || q.active;
         }
-        // No live path anywhere in the wave: every slot asked and got nothing, so the current
-        // pool is handed out, every opened pool is complete (and resolved), the queue drained.
+        // No live path anywhere in the wave: every slot asked and got nothing, so the pool is
+        // used up and the global queue drained (an entry shortage needs live paths to exist).
         if (__ballot(any_active) == 0ull) break;
         [[maybe_unused]] const unsigned long long t1 = DBG_STAMP();
 
@@ -651,9 +620,9 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
             bool finished = false;
             if (q.active) {
                 ++n_segments;
+                unsigned long long* acc = lds_acc + q.entry * kAccWords;
                 if (best_i[r] < 0) {
                     const f3 rad = sky_radiance(q.p);
-                    unsigned long long* acc = lds_acc + q.live_acc * kAccWords;
                     atomicAdd(acc + 0, to_fixed(rad.x));  // ds_add_u64: order-independent integer sum
                     atomicAdd(acc + 1, to_fixed(rad.y));
                     atomicAdd(acc + 2, to_fixed(rad.z));
@@ -674,27 +643,27 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
                         finished = true;  // depth exhausted: radiance 0
                     }
                 }
-                if (finished) q.active = false;
             }
-            // count finished samples per generation (wave-uniform)
-            const uint32_t fgen = q.live_acc / kGenPix;
-#pragma unroll
-            for (uint32_t k = 0; k < static_cast<uint32_t>(kGens); ++k)
-                gen_done[k] += static_cast<uint32_t>(__popcll(__ballot(finished && fgen == k)));
-        }
-        // ---- resolve complete generations: coalesced RGBA8 stores -----------------
-#pragma unroll
-        for (uint32_t k = 0; k < static_cast<uint32_t>(kGens); ++k) {
-            if (gen_total[k] != 0u && gen_done[k] == gen_total[k]) {
-                if (lane < gen_npix[k]) {
-                    const unsigned long long* acc = lds_acc + (k * kGenPix + lane) * kAccWords;
-                    const uint32_t pix = gen_first[k] + lane;
-                    const uint32_t lr = pix / a.width, i = pix - lr * a.width;
+            // A finished sample bumps its pixel's counter; the lane that completes the pixel
+            // resolves it.  All adds to the entry were issued by earlier LDS instructions of
+            // this wave (or serialised within this one), so the sums it reads are final.
+            bool completed = false;
+            if (finished) {
+                q.active = false;
+                unsigned long long* acc = lds_acc + q.entry * kAccWords;
+                const unsigned long long before = atomicAdd(acc + 3, 1ull);
+                if (before + 1ull == a.spp) {
+                    completed = true;
+                    const uint32_t lr = q.pix / a.width, i = q.pix - lr * a.width;
                     a.dst[static_cast<size_t>(lr) * a.dst_stride + i] =
                         resolve_pixel(acc[0], acc[1], acc[2], a.spp, a.quantiser);
                 }
-                gen_total[k] = 0u;  // ring slot free again
-                if (k == cur) cur_total = cur_handed = 0u;
+            }
+            unsigned long long done_mask = __ballot(completed);
+            while (done_mask != 0ull) {  // return the entries of completed pixels (0-2 per iteration)
+                const int l = __builtin_ctzll(done_mask);
+                done_mask &= done_mask - 1ull;
+                free_entries |= 1ull << __builtin_amdgcn_readlane(q.entry, l);
             }
         }
         DBG_ADD(dbg_t_refill, t1 - t0);
@@ -783,12 +752,12 @@ hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, in
     }
     PersistArgs g{};
     g.n_pad = (a.n + kBlockSph - 1u) / kBlockSph * kBlockSph;
-    g.max_take = max_take == 0u ? 8u : (max_take > 4096u ? 4096u : max_take);
+    (void)max_take;  // scheduling is per sample now; the hint is accepted and ignored
     g.total_pix = a.local_rows * a.width;
-    g.pool_pix = 2048u / a.spp;
-    g.pool_pix = g.pool_pix < 1u ? 1u : (g.pool_pix > kGenPix ? kGenPix : g.pool_pix);
+    g.pool_pix = 2048u / a.spp;  // ~2048 samples per pool away from the tail
+    g.pool_pix = g.pool_pix < 1u ? 1u : (g.pool_pix > 256u ? 256u : g.pool_pix);
     // LDS per workgroup: the padded sphere list (16 B each); while the list is small, the
-    // shading records too (32 B each); and 3 KiB of pixel accumulators per wave.
+    // shading records too (32 B each); and 2 KiB of pixel accumulator entries per wave.
     const size_t lds_geo = static_cast<size_t>(g.n_pad) * sizeof(float4);
     const bool shade_lds = lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 24u * 1024u;
     const size_t lds_scene = lds_geo + (shade_lds ? static_cast<size_t>(a.n) * sizeof(ShadeRec) : 0u);
