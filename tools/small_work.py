@@ -13,7 +13,9 @@ with V.Context(0) as ctx:
     ctx.set_scene(sph, mat)
     base, segs0 = run(ctx, 1200, 800, 100)
     print(f"1200x800x100 full        {base:7.2f} ms  {segs0/base/1e6:8.1f} Mseg/ms-1")
-    for name, args, kw in [("1200x800x50 full", (1200, 800, 50), {}), ("1200x800x25 full", (1200, 800, 25), {}),
+    cases = [("1200x800x100 tile 0/8 blk4", (1200, 800, 100), dict(row_block=4, tile_rank=0, tile_count=8)),
+             ("1200x800x100 tile 0/2 blk4", (1200, 800, 100), dict(row_block=4, tile_rank=0, tile_count=2))] if "brief" in sys.argv else None
+    for name, args, kw in cases or [("1200x800x50 full", (1200, 800, 50), {}), ("1200x800x25 full", (1200, 800, 25), {}),
                            ("1200x800x12 full", (1200, 800, 12), {}),
                            ("1200x400x100 full", (1200, 400, 100), {}), ("600x400x100 full", (600, 400, 100), {}),
                            ("1200x800x100 tile 0/2 blk4", (1200, 800, 100), dict(row_block=4, tile_rank=0, tile_count=2)),

@@ -13,6 +13,8 @@
 // against the independent CPU restatement in oracle/.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "rtiow_device.h"
 #include "rtiow_rng.h"
 
@@ -382,6 +384,23 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 //            per-lane candidate word by one v_alignbit.  Only candidates (about
 //            two per ray) take the sqrt/root path, per lane, after each block of
 //            32 spheres.
+//   sparse   path lengths are heavy-tailed (mean 2.8 segments, 0.1 % reach depth 50
+//            inside glass), so once the queue is empty a wave is left with a
+//            handful of long paths, and a lock-step iteration costs the same for
+//            1 live lane as for 128.  With at most kSparseMax live paths the
+//            wave turns the loop inside out: for each live path in turn, the 64
+//            LANES take 64 different spheres per step (conflict-free ds_read_b128),
+//            each lane keeps the closest of its own, and a 6-step wave reduction
+//            on the (root, index) key finds the hit — the same minimum with the
+//            same tie rule, ~20x sooner than a lock-step pass.
+//   merge    ... and before that, the waves of a workgroup pool their leftovers:
+//            a wave that has nothing left to start and at most kDonateMax live
+//            paths parks them in a workgroup-shared LDS area and exits; the last
+//            wave of the group to get there adopts them all (LDS keeps the
+//            donors' pixel accumulators alive and addressable), so the tail of
+//            4-16 waves costs one wave's iterations instead of 4-16.  No wave
+//            waits on another's work: arrival order comes from one returning
+//            ds_add, and the adopter only waits for donors to finish writing.
 //   shade    miss -> sky radiance, converted to fixed point and added to the
 //            pixel's LDS accumulator (ds_add_u64; integer sums do not depend on
 //            order); hit -> scatter by material (shading records in LDS too
@@ -400,6 +419,10 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 
 constexpr int kSlots = 2;           // path slots per lane
 constexpr uint32_t kBlockSph = 32;  // spheres per candidate word
+constexpr uint32_t kSparseMax = 16; // live paths per wave at or below which the sphere-parallel trace runs
+constexpr uint32_t kTailPool = 112; // paths a workgroup's tail pool holds (the adopter keeps <= 16 of its own)
+constexpr uint32_t kTailRecWords = 16;  // 64-byte parked-path records
+constexpr uint32_t kTailBytes = 16u + kTailPool * kTailRecWords * 4u;  // counters + records
 constexpr uint32_t kAccEntries = 64;                 // pixels a wave may have in flight
 constexpr uint32_t kAccWords = 4;                    // u64 words per entry: r, g, b, samples done
 constexpr uint32_t kWaveAccBytes = kAccEntries * kAccWords * 8u;  // 2 KiB of LDS per wave
@@ -407,7 +430,7 @@ constexpr uint32_t kWaveAccBytes = kAccEntries * kAccWords * 8u;  // 2 KiB of LD
 struct Slot {
     Path p;
     uint32_t pix;    // local pixel of the path in flight
-    uint32_t entry;  // its accumulator entry
+    uint32_t entry;  // its accumulator entry, numbered across the workgroup: wave * kAccEntries + index
     uint32_t depth;
     bool active;
 };
@@ -499,6 +522,61 @@ DI void trace_slots(const float4* lds, uint32_t n_pad, uint32_t n, Slot (&sl)[R]
     }
 }
 
+// Sphere-parallel closest hit for a wave with few live paths: see "sparse" above.  Each lane scans
+// the spheres lane, lane+64, ... in ascending order with the oracle's per-sphere rule (near root if
+// it lies beyond t_min, else the far root) and a strict '<', so within a lane a tie keeps the lower
+// index; the wave reduction takes the minimum of (root bits << 32 | index), which orders positive
+// floats numerically and breaks ties towards the lower index as well.
+template <int R>
+DI void trace_sparse(const float4* lds, uint32_t n_pad, uint32_t n, Slot (&sl)[R], float (&best)[R],
+                     int (&best_i)[R]) {
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        best[r] = __builtin_inff();
+        best_i[r] = -1;
+        unsigned long long live = __ballot(sl[r].active);
+        while (live != 0ull) {
+            const int src = __builtin_ctzll(live);
+            live &= live - 1ull;
+            const Path& p = sl[r].p;
+            const float ox = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.o.x), src));
+            const float oy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.o.y), src));
+            const float oz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.o.z), src));
+            const float dx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.du.x), src));
+            const float dy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.du.y), src));
+            const float dz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.du.z), src));
+            float bs = __builtin_inff();
+            uint32_t bi = 0xFFFFFFFFu;
+            for (uint32_t j = lane; j < n_pad; j += 64u) {
+                const float4 s = lds[j];
+                const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
+                const float hb = fma_(ocz, dz, fma_(ocy, dy, ocx * dx));
+                const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
+                const float disc = fma_(hb, hb, -cc);
+                const bool cand = !__builtin_signbit(disc) && disc == disc && j < n;
+                const float sq = __builtin_sqrtf(cand ? disc : 0.0f);
+                float root = -hb - sq;
+                root = root > kTMin ? root : -hb + sq;
+                if (cand && root > kTMin && root < bs) {
+                    bs = root;
+                    bi = j;
+                }
+            }
+            unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(bs)) << 32) | bi;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long other = __shfl_xor(key, off);
+                key = other < key ? other : key;
+            }
+            if (lane == static_cast<uint32_t>(src) && static_cast<uint32_t>(key) != 0xFFFFFFFFu) {
+                best[r] = __uint_as_float(static_cast<uint32_t>(key >> 32));
+                best_i[r] = static_cast<int>(static_cast<uint32_t>(key));
+            }
+        }
+    }
+}
+
 DI uint32_t lane_rank(unsigned long long mask) {  // number of set bits of mask below this lane
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
@@ -508,8 +586,13 @@ template <bool SHADE_LDS>
 __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, PersistArgs g) {
     extern __shared__ float4 lds_spheres[];
     float4* lds_shade = lds_spheres + g.n_pad;  // SHADE_LDS: 2 x float4 per sphere
-    unsigned long long* lds_acc = reinterpret_cast<unsigned long long*>(lds_shade + (SHADE_LDS ? 2u * a.n : 0u)) +
-                                  (threadIdx.x / 64u) * (kWaveAccBytes / 8u);  // this wave's accumulator entries
+    // accumulator entries of every wave of the workgroup (a wave allocates only from its own 64), then
+    // the tail pool: {parked, arrived, pad, pad} + kTailPool records
+    unsigned long long* lds_acc = reinterpret_cast<unsigned long long*>(lds_shade + (SHADE_LDS ? 2u * a.n : 0u));
+    const uint32_t waves_in_group = blockDim.x / 64u;
+    const uint32_t wave_in_group = threadIdx.x / 64u;
+    uint32_t* lds_tail = reinterpret_cast<uint32_t*>(lds_acc + waves_in_group * (kWaveAccBytes / 8u));
+    if (threadIdx.x < 4u) lds_tail[threadIdx.x] = 0u;
     stage_spheres(a, lds_spheres, g.n_pad);
     if (SHADE_LDS) {
         const float4* src = reinterpret_cast<const float4*>(a.shade);
@@ -531,8 +614,12 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
     uint32_t cur_s = a.spp;                  // its next sample; == spp: no pixel open
     unsigned long long free_entries = ~0ull; // accumulator entries not in use
     bool exhausted = false;                  // the global queue has been drained
+    bool tail_done = false;                  // this wave has been through the workgroup's tail merge
+    // a wave parks at most kDonateMax paths, so that all donors fit the pool
+    const uint32_t donate_max = waves_in_group > 1u ? (kTailPool / (waves_in_group - 1u) < kSparseMax
+                                                            ? kTailPool / (waves_in_group - 1u) : kSparseMax) : 0u;
     uint32_t n_paths = 0, n_segments = 0;
-    [[maybe_unused]] uint32_t dbg_slow_trips = 0, dbg_cands = 0, dbg_iters = 0;
+    [[maybe_unused]] uint32_t dbg_slow_trips = 0, dbg_cands = 0, dbg_iters = 0, dbg_sparse = 0;
     [[maybe_unused]] unsigned long long dbg_t_refill = 0, dbg_t_trace = 0, dbg_t_slow = 0, dbg_t_shade = 0;
     [[maybe_unused]] const unsigned long long dbg_c0 = DBG_STAMP();
 #ifdef RTIOW_DEBUG_COUNTERS
@@ -579,12 +666,12 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
                     free_entries &= free_entries - 1ull;
                     cur_pix = pool_next++;
                     cur_s = 0u;
-                    if (lane < kAccWords) lds_acc[cur_entry * kAccWords + lane] = 0ull;
+                    if (lane < kAccWords) lds_acc[(wave_in_group * kAccEntries + cur_entry) * kAccWords + lane] = 0ull;
                 }
                 const uint32_t n = want - served < a.spp - cur_s ? want - served : a.spp - cur_s;
                 if (!q.active && rank >= served && rank < served + n) {
                     q.pix = cur_pix;
-                    q.entry = cur_entry;
+                    q.entry = wave_in_group * kAccEntries + cur_entry;
                     my_s = cur_s + (rank - served);
                     got_sample = true;
                 }
@@ -601,6 +688,80 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
             }
             any_active = any_active || q.active;
         }
+        // ---- tail merge: pool the workgroup's leftovers in one wave ----------------------
+        if (!tail_done && donate_max != 0u && exhausted && pool_next == pool_end && cur_s == a.spp) {
+            uint32_t live = 0u;
+#pragma unroll
+            for (int r = 0; r < kSlots; ++r) live += static_cast<uint32_t>(__popcll(__ballot(sl[r].active)));
+            if (live <= donate_max) {
+                tail_done = true;
+                uint32_t order = 0u;
+                if (lane == 0u) order = atomicAdd(&lds_tail[1], 1u);  // returning ds_add: arrival order
+                order = __builtin_amdgcn_readfirstlane(order);
+                float* recs = reinterpret_cast<float*>(lds_tail + 4);
+                if (order + 1u != waves_in_group) {
+                    // donor: park the live paths (records first, then the count they become visible by)
+                    uint32_t base = 0u;
+                    if (lane == 0u && live != 0u) base = atomicAdd(&lds_tail[0], live);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    uint32_t done = 0u;
+#pragma unroll
+                    for (int r = 0; r < kSlots; ++r) {
+                        Slot& q = sl[r];
+                        const unsigned long long m = __ballot(q.active);
+                        if (q.active) {
+                            float* rec = recs + (base + done + lane_rank(m)) * kTailRecWords;
+                            rec[0] = q.p.o.x; rec[1] = q.p.o.y; rec[2] = q.p.o.z;
+                            rec[3] = q.p.du.x; rec[4] = q.p.du.y; rec[5] = q.p.du.z;
+                            rec[6] = q.p.att.x; rec[7] = q.p.att.y; rec[8] = q.p.att.z;
+                            rec[9] = __uint_as_float(q.p.rng.state);
+                            rec[10] = __uint_as_float(q.depth);
+                            rec[11] = __uint_as_float(q.pix);
+                            rec[12] = __uint_as_float(q.entry);
+                            rec[13] = __uint_as_float(1u);  // valid
+                            q.active = false;
+                        }
+                        done += static_cast<uint32_t>(__popcll(m));
+                    }
+                    // published: a wave's LDS operations are performed in order, so the records are
+                    // in place before this tick
+                    if (lane == 0u) atomicAdd(&lds_tail[2], 1u);
+                    break;  // nothing left for this wave; its accumulators live on in LDS
+                }
+                // adopter: every other wave of the group took an earlier arrival tick and is past its
+                // decision; wait (briefly) until each has published, then take everything
+                for (;;) {
+                    uint32_t published = 0u;
+                    if (lane == 0u) published = atomicAdd(&lds_tail[2], 0u);
+                    if (__builtin_amdgcn_readfirstlane(published) + 1u == waves_in_group) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                uint32_t parked = 0u;
+                if (lane == 0u) parked = atomicAdd(&lds_tail[0], 0u);
+                parked = __builtin_amdgcn_readfirstlane(parked);
+                uint32_t taken = 0u;
+#pragma unroll
+                for (int r = 0; r < kSlots; ++r) {
+                    Slot& q = sl[r];
+                    const unsigned long long idle = __ballot(!q.active);
+                    const uint32_t k = taken + lane_rank(idle);
+                    if (!q.active && k < parked) {
+                        const float* rec = recs + k * kTailRecWords;
+                        q.p.o = mk(rec[0], rec[1], rec[2]);
+                        q.p.du = mk(rec[3], rec[4], rec[5]);
+                        q.p.att = mk(rec[6], rec[7], rec[8]);
+                        q.p.rng = Pcg(__float_as_uint(rec[9]));
+                        q.depth = __float_as_uint(rec[10]);
+                        q.pix = __float_as_uint(rec[11]);
+                        q.entry = __float_as_uint(rec[12]);
+                        q.active = true;
+                    }
+                    const uint32_t room = static_cast<uint32_t>(__popcll(idle));
+                    taken += room < parked - taken ? room : parked - taken;
+                    any_active = any_active || q.active;
+                }
+            }
+        }
         // No live path anywhere in the wave: every slot asked and got nothing, so the pool is
         // used up and the global queue drained (an entry shortage needs live paths to exist).
         if (__ballot(any_active) == 0ull) break;
@@ -609,7 +770,15 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
         // ---- trace ----------------------------------------------------------
         float best[kSlots];
         int best_i[kSlots];
-        trace_slots<kSlots>(lds_spheres, g.n_pad, a.n, sl, best, best_i, dbg_slow_trips, dbg_cands, dbg_t_slow);
+        uint32_t live_paths = 0u;
+#pragma unroll
+        for (int r = 0; r < kSlots; ++r) live_paths += static_cast<uint32_t>(__popcll(__ballot(sl[r].active)));
+        if (live_paths <= kSparseMax) {
+            trace_sparse<kSlots>(lds_spheres, g.n_pad, a.n, sl, best, best_i);
+            DBG_ADD(dbg_sparse, lane == 0u ? 1u : 0u);
+        } else {
+            trace_slots<kSlots>(lds_spheres, g.n_pad, a.n, sl, best, best_i, dbg_slow_trips, dbg_cands, dbg_t_slow);
+        }
         DBG_ADD(dbg_iters, lane == 0u ? 1u : 0u);
         [[maybe_unused]] const unsigned long long t2 = DBG_STAMP();
 
@@ -663,7 +832,8 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
             while (done_mask != 0ull) {  // return the entries of completed pixels (0-2 per iteration)
                 const int l = __builtin_ctzll(done_mask);
                 done_mask &= done_mask - 1ull;
-                free_entries |= 1ull << __builtin_amdgcn_readlane(q.entry, l);
+                const uint32_t e = __builtin_amdgcn_readlane(q.entry, l);
+                if (e / kAccEntries == wave_in_group) free_entries |= 1ull << (e % kAccEntries);  // adopted pixels: not ours to reuse
             }
         }
         DBG_ADD(dbg_t_refill, t1 - t0);
@@ -685,6 +855,8 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
     atomicAdd(&a.counters->debug[0], static_cast<unsigned long long>(dbg_slow_trips));
     atomicAdd(&a.counters->debug[1], static_cast<unsigned long long>(dbg_cands));
     atomicAdd(&a.counters->debug[2], static_cast<unsigned long long>(dbg_iters));
+    // sparse iterations are reported in the high half of debug[2]
+    atomicAdd(&a.counters->debug[2], static_cast<unsigned long long>(dbg_sparse) << 32);
     if (lane == 0u) {  // per-wave cycle shares: [3] refill [4] trace (incl. slow) [5] slow [6] shade
         atomicAdd(&a.counters->debug[3], dbg_t_refill);
         atomicAdd(&a.counters->debug[4], dbg_t_trace);
@@ -757,13 +929,13 @@ hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, in
     g.pool_pix = 2048u / a.spp;  // ~2048 samples per pool away from the tail
     g.pool_pix = g.pool_pix < 1u ? 1u : (g.pool_pix > 256u ? 256u : g.pool_pix);
     // LDS per workgroup: the padded sphere list (16 B each); while the list is small, the
-    // shading records too (32 B each); and 2 KiB of pixel accumulator entries per wave.
+    // shading records too (32 B each); 2 KiB of pixel accumulator entries per wave and the 7 KiB tail pool.
     const size_t lds_geo = static_cast<size_t>(g.n_pad) * sizeof(float4);
     const bool shade_lds = lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 24u * 1024u;
     const size_t lds_scene = lds_geo + (shade_lds ? static_cast<size_t>(a.n) * sizeof(ShadeRec) : 0u);
     // small scenes -> 256-thread groups; large ones -> 1024-thread groups so 16 waves share one copy
     const uint32_t threads = lds_scene <= 24u * 1024u ? 256u : 1024u;
-    const size_t lds = lds_scene + static_cast<size_t>(threads / 64u) * kWaveAccBytes;
+    const size_t lds = lds_scene + static_cast<size_t>(threads / 64u) * kWaveAccBytes + kTailBytes;
     auto kernel_fn = shade_lds ? path_persistent_kernel<true> : path_persistent_kernel<false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -777,6 +949,7 @@ hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, in
     const unsigned long long samples = static_cast<unsigned long long>(g.total_pix) * a.spp;
     const unsigned long long want_blocks = (samples + threads * kSlots - 1) / (threads * kSlots);
     if (grid > want_blocks) grid = want_blocks;
+    if (const char* v = getenv("RTIOW_DEBUG_GRID")) grid = strtoul(v, nullptr, 10);  // tuning only
     if (grid < 1) grid = 1;
     g.total_waves = static_cast<uint32_t>(grid) * (threads / 64u);
     hipLaunchKernelGGL(kernel_fn, dim3(static_cast<uint32_t>(grid)), dim3(threads), lds, stream, a, g);
