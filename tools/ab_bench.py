@@ -10,10 +10,10 @@ args = [a for a in sys.argv[1:] if a.endswith(".so")]
 spp = int(sys.argv[sys.argv.index("--spp") + 1]) if "--spp" in sys.argv else 100
 rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 5
 grid = int(sys.argv[sys.argv.index("--grid") + 1]) if "--grid" in sys.argv else 11
+kernels = [int(k) for k in sys.argv[sys.argv.index("--kernels") + 1].split(",")] if "--kernels" in sys.argv else [0]
 w, h = (1200, 800)
 sph, mat = V.make_cover_scene(1, grid)
 cam = V.make_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, w / h, 0.1, 10.0)
-prm = V.make_params(w, h, spp=spp, max_depth=50, seed=1)
 libs = []
 for path in args:
     lib = C.CDLL(os.path.abspath(path))
@@ -26,16 +26,20 @@ for path in args:
     libs.append((path, lib, h_))
 import numpy as np
 out = np.zeros((h, w, 4), np.uint8)
-times = {p: [] for p, _, _ in libs}
+libs = [(f"{p}:k{k}", lib, h_, k) for p, lib, h_ in libs for k in kernels]
+times = {p: [] for p, _, _, _ in libs}
+tests = {}
 crc = {}
 for r in range(rounds + 1):
-    for path, lib, h_ in libs:
+    for path, lib, h_, k in libs:
+        prm = V.make_params(w, h, spp=spp, max_depth=50, seed=1, kernel=k)
         assert lib.rtRender(h_, C.byref(cam), C.byref(prm), out.ctypes.data, w * 4, 0, None) == 0
         st = V.RtStats()
         lib.rtGetStats(h_, C.byref(st))
         if r:
             times[path].append(st.kernel_ms)
         crc[path] = int(out.view(np.uint32).sum())
+        tests[path] = st.sphere_tests / max(1, st.segments)
 for p in times:
     t = times[p]
-    print(f"{os.path.basename(p):40s} median {statistics.median(t):8.3f} ms  min {min(t):8.3f}  frame-sum {crc[p]}")
+    print(f"{os.path.basename(p):40s} median {statistics.median(t):8.3f} ms  min {min(t):8.3f}  frame-sum {crc[p]}  tests/segment {tests[p]:.1f}")

@@ -21,6 +21,10 @@ struct RtContext {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     float4* d_spheres = nullptr;
     rtiow::ShadeRec* d_shade = nullptr;
+    float4* d_cslots = nullptr;   // clustered list (rtiow_clusters.cpp)
+    uint32_t* d_cidx = nullptr;
+    float4* d_cbounds = nullptr;
+    uint32_t n_clusters = 0;
     uint32_t n_spheres = 0;
     rtiow::Counters* d_counters = nullptr;
     rtiow::Counters* h_counters = nullptr;  // pinned
@@ -119,6 +123,9 @@ int rtDestroy(RtContext* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_spheres) (void)hipFree(ctx->d_spheres);
     if (ctx->d_shade) (void)hipFree(ctx->d_shade);
+    if (ctx->d_cslots) (void)hipFree(ctx->d_cslots);
+    if (ctx->d_cidx) (void)hipFree(ctx->d_cidx);
+    if (ctx->d_cbounds) (void)hipFree(ctx->d_cbounds);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
@@ -175,6 +182,22 @@ int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materi
     delete[] tmp;
     if (e != hipSuccess) return fail_hip(ctx, e, "hipMemcpy(shading records)");
     RT_HIP(ctx, hipMemcpy(ctx->d_spheres, spheres, sizeof(float4) * n_spheres, hipMemcpyHostToDevice));
+    // two-level list for the clustered kernel
+    rtiow::ClusterScene cs;
+    rtiow::build_clusters(spheres, n_spheres, cs);
+    if (ctx->d_cslots) RT_HIP(ctx, hipFree(ctx->d_cslots));
+    if (ctx->d_cidx) RT_HIP(ctx, hipFree(ctx->d_cidx));
+    if (ctx->d_cbounds) RT_HIP(ctx, hipFree(ctx->d_cbounds));
+    ctx->d_cslots = nullptr;
+    ctx->d_cidx = nullptr;
+    ctx->d_cbounds = nullptr;
+    RT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_cslots), sizeof(float4) * cs.slots.size()));
+    RT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_cidx), sizeof(uint32_t) * cs.idx.size()));
+    RT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_cbounds), sizeof(float4) * cs.bounds.size()));
+    RT_HIP(ctx, hipMemcpy(ctx->d_cslots, cs.slots.data(), sizeof(float4) * cs.slots.size(), hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemcpy(ctx->d_cidx, cs.idx.data(), sizeof(uint32_t) * cs.idx.size(), hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemcpy(ctx->d_cbounds, cs.bounds.data(), sizeof(float4) * cs.bounds.size(), hipMemcpyHostToDevice));
+    ctx->n_clusters = cs.n_clusters;
     ctx->n_spheres = n_spheres;
     return RT_OK;
 }
@@ -229,6 +252,10 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         rtiow::PathArgs a{};
         a.spheres = ctx->d_spheres;
         a.shade = ctx->d_shade;
+        a.cslots = ctx->d_cslots;
+        a.cidx = ctx->d_cidx;
+        a.cbounds = ctx->d_cbounds;
+        a.n_clusters = ctx->n_clusters;
         a.n = ctx->n_spheres;
         a.cam = *cam;
         a.width = W;
@@ -319,7 +346,10 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
         ctx->stats.kernel_ms = ms;
         ctx->stats.paths = ctx->h_counters->paths;
         ctx->stats.segments = ctx->h_counters->segments;
-        ctx->stats.sphere_tests = ctx->stats.segments * ctx->stats.n_spheres;
+        // persistent kernels count the tests they perform; the one-lane-per-pixel kernel tests every
+        // sphere for every segment
+        ctx->stats.sphere_tests = ctx->h_counters->tests ? ctx->h_counters->tests
+                                                         : ctx->stats.segments * ctx->stats.n_spheres;
         for (int k = 0; k < 8; ++k) ctx->stats.debug[k] = ctx->h_counters->debug[k];
     }
     *out = ctx->stats;

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <vector>
 
 #include "../../include/rtiow.h"
 
@@ -14,7 +15,7 @@ struct Counters {
     unsigned long long segments;
     unsigned int queue_head_pix;    // persistent kernel: next pixel of the global pool queue
     unsigned int pad32;
-    unsigned long long pad;
+    unsigned long long tests;       // ray-sphere and ray-bound tests performed
     unsigned long long debug[8];    // diagnostic builds (-DRTIOW_DEBUG_COUNTERS) only
 };
 
@@ -27,10 +28,18 @@ struct ShadeRec {
     uint32_t pad[2];
 };
 
+// Two-level sphere list of the clustered kernel (rtiow_clusters.cpp): clusters of kClusterSize
+// members, kClusterStride slots apart (the odd stride staggers the LDS banks of different clusters).
+constexpr uint32_t kClusterSize = 16, kClusterStride = 17;
+
 struct PathArgs {
     const float4* spheres;       // n x {cx,cy,cz,radius} as uploaded (RtSphere)
     const ShadeRec* shade;       // n x 32 B
     uint32_t n;
+    const float4* cslots;        // clustered: n_clusters x kClusterStride x {cx,cy,cz,r*r}; padding never hit
+    const uint32_t* cidx;        // clustered: original index of every slot (0xFFFFFFFF = padding)
+    const float4* cbounds;       // clustered: n_clusters x {Cx,Cy,Cz,R*R}
+    uint32_t n_clusters;         // multiple of 8
     RtCamera cam;
     uint32_t width, height;      // full image
     uint32_t spp, max_depth, seed, quantiser;
@@ -51,10 +60,22 @@ struct ChArgs {
 };
 
 // kernel variants selectable through RtParams.kernel (identical results)
+struct ClusterF4 {
+    float x, y, z, w;
+};
+struct ClusterScene {  // host-side result of build_clusters
+    std::vector<ClusterF4> slots;
+    std::vector<uint32_t> idx;
+    std::vector<ClusterF4> bounds;
+    uint32_t n_clusters = 0;
+};
+void build_clusters(const RtSphere* spheres, uint32_t n, ClusterScene& out);
+
 enum : uint32_t {
     KERNEL_DEFAULT = 0,
     KERNEL_PIXEL = 1,      // one lane per pixel, spp loop inside (v1)
-    KERNEL_PERSISTENT = 2  // persistent waves + sample queue + ballot refill (v2)
+    KERNEL_PERSISTENT = 2, // persistent waves, flat sphere list (every ray tests every sphere)
+    KERNEL_CLUSTERED = 3   // persistent waves, two-level list: cluster bounds, then members per lane
 };
 
 hipError_t launch_ch(const ChArgs& a, hipStream_t stream);

@@ -527,14 +527,17 @@ DI void trace_slots(const float4* lds, uint32_t n_pad, uint32_t n, Slot (&sl)[R]
 // it lies beyond t_min, else the far root) and a strict '<', so within a lane a tie keeps the lower
 // index; the wave reduction takes the minimum of (root bits << 32 | index), which orders positive
 // floats numerically and breaks ties towards the lower index as well.
+// `list` is the flat list (idx_map == nullptr: slot == sphere index) or the clustered list's slots
+// (idx_map gives the original index, 0xFFFFFFFF for padding).  Results: best_i = slot, best_o = index.
 template <int R>
-DI void trace_sparse(const float4* lds, uint32_t n_pad, uint32_t n, Slot (&sl)[R], float (&best)[R],
-                     int (&best_i)[R]) {
+DI void trace_sparse(const float4* list, const uint32_t* idx_map, uint32_t n_slots, uint32_t n, Slot (&sl)[R],
+                     float (&best)[R], int (&best_i)[R], uint32_t (&best_o)[R]) {
     const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         best[r] = __builtin_inff();
         best_i[r] = -1;
+        best_o[r] = 0u;
         unsigned long long live = __ballot(sl[r].active);
         while (live != 0ull) {
             const int src = __builtin_ctzll(live);
@@ -546,34 +549,137 @@ DI void trace_sparse(const float4* lds, uint32_t n_pad, uint32_t n, Slot (&sl)[R
             const float dx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.du.x), src));
             const float dy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.du.y), src));
             const float dz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.du.z), src));
-            float bs = __builtin_inff();
-            uint32_t bi = 0xFFFFFFFFu;
-            for (uint32_t j = lane; j < n_pad; j += 64u) {
-                const float4 s = lds[j];
+            unsigned long long key = ~0ull;  // (root bits << 32) | original index
+            uint32_t kslot = 0u;
+            for (uint32_t j = lane; j < n_slots; j += 64u) {
+                const float4 s = list[j];
+                const uint32_t orig = idx_map ? idx_map[j] : j;
                 const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
                 const float hb = fma_(ocz, dz, fma_(ocy, dy, ocx * dx));
                 const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
                 const float disc = fma_(hb, hb, -cc);
-                const bool cand = !__builtin_signbit(disc) && disc == disc && j < n;
+                const bool cand = !__builtin_signbit(disc) && disc == disc && orig < n;
                 const float sq = __builtin_sqrtf(cand ? disc : 0.0f);
                 float root = -hb - sq;
                 root = root > kTMin ? root : -hb + sq;
-                if (cand && root > kTMin && root < bs) {
-                    bs = root;
-                    bi = j;
+                const unsigned long long k2 = (static_cast<unsigned long long>(__float_as_uint(root)) << 32) | orig;
+                if (cand && root > kTMin && k2 < key) {
+                    key = k2;
+                    kslot = j;
                 }
             }
-            unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(bs)) << 32) | bi;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 const unsigned long long other = __shfl_xor(key, off);
-                key = other < key ? other : key;
+                const uint32_t oslot = __shfl_xor(kslot, off);
+                if (other < key) {
+                    key = other;
+                    kslot = oslot;
+                }
             }
-            if (lane == static_cast<uint32_t>(src) && static_cast<uint32_t>(key) != 0xFFFFFFFFu) {
+            if (lane == static_cast<uint32_t>(src) && key != ~0ull) {
                 best[r] = __uint_as_float(static_cast<uint32_t>(key >> 32));
-                best_i[r] = static_cast<int>(static_cast<uint32_t>(key));
+                best_i[r] = static_cast<int>(kslot);
+                best_o[r] = static_cast<uint32_t>(key);
             }
         }
+    }
+}
+
+// Two-level closest hit (SURVEY f-4).  Phase 1, wave in lock-step: every cluster bound against every
+// live ray (LDS broadcast), one candidate bit per cluster — bound reached in front of the origin, or
+// origin inside it.  Phase 2, lane by lane: the 16 members of each candidate cluster; lanes read
+// their own cluster, rotated by the lane number so that the 16 lanes of an LDS access group touch 16
+// different bank quads whatever clusters they are on.  Members go through the same discriminant /
+// candidate-word / first-root-beyond-t_min rule as the flat list, and the hit is the minimum of
+// (root bits << 32 | original index): the same sphere the flat scan returns, ties included.
+DI void examine_keyed(const float4* slots, const uint32_t* idx_map, uint32_t slot, const Path& p,
+                      unsigned long long& key, uint32_t& kslot) {
+    const uint32_t orig = idx_map[slot];
+    if (orig == 0xFFFFFFFFu) return;  // padding
+    const float4 s = slots[slot];
+    const float ocx = p.o.x - s.x, ocy = p.o.y - s.y, ocz = p.o.z - s.z;
+    const float hb = fma_(ocz, p.du.z, fma_(ocy, p.du.y, ocx * p.du.x));
+    const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
+    const float disc = fma_(hb, hb, -cc);
+    if (__builtin_signbit(disc) || disc != disc) return;
+    const float sq = __builtin_sqrtf(disc);
+    float root = -hb - sq;
+    root = root > kTMin ? root : -hb + sq;
+    if (!(root > kTMin)) return;
+    const unsigned long long k2 = (static_cast<unsigned long long>(__float_as_uint(root)) << 32) | orig;
+    if (k2 < key) {
+        key = k2;
+        kslot = slot;
+    }
+}
+
+template <int R>
+DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const float4* bounds, uint32_t n_clusters,
+                        Slot (&sl)[R], float (&best)[R], int (&best_i)[R], uint32_t (&best_o)[R],
+                        uint32_t& n_tests) {
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long key[R];
+    uint32_t kslot[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        key[r] = ~0ull;
+        kslot[r] = 0u;
+    }
+    for (uint32_t g0 = 0; g0 < n_clusters; g0 += 32u) {
+        uint32_t cmask[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) cmask[r] = 0u;
+        const uint32_t jn = n_clusters - g0 < 32u ? n_clusters - g0 : 32u;  // n_clusters is a multiple of 8
+#pragma unroll 8
+        for (uint32_t j = 0; j < jn; ++j) {
+            const float4 b = bounds[g0 + j];  // wave-uniform address: LDS broadcast
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const Path& p = sl[r].p;
+                const float ocx = p.o.x - b.x, ocy = p.o.y - b.y, ocz = p.o.z - b.z;
+                const float hb = fma_(ocz, p.du.z, fma_(ocy, p.du.y, ocx * p.du.x));
+                const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -b.w)));
+                const float disc = fma_(hb, hb, -cc);
+                const bool reach = !__builtin_signbit(disc) && disc == disc && (hb < 0.0f || cc < 0.0f);
+                cmask[r] = (cmask[r] << 1) | (reach ? 1u : 0u);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uint32_t cm = sl[r].active ? cmask[r] << (32u - jn) : 0u;  // first cluster of the word at bit 31
+            if (sl[r].active) n_tests += jn;
+            while (cm) {  // per lane: its own candidate clusters
+                const uint32_t bit = static_cast<uint32_t>(__builtin_clz(cm));
+                cm &= ~(0x80000000u >> bit);
+                const uint32_t base = (g0 + bit) * kClusterStride;
+                const Path& p = sl[r].p;
+                uint32_t miss = 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < kClusterSize; ++k) {
+                    const float4 s = slots[base + ((k + lane) & (kClusterSize - 1u))];
+                    const float ocx = p.o.x - s.x, ocy = p.o.y - s.y, ocz = p.o.z - s.z;
+                    const float hb = fma_(ocz, p.du.z, fma_(ocy, p.du.y, ocx * p.du.x));
+                    const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
+                    const float disc = fma_(hb, hb, -cc);
+                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(disc), 31);
+                }
+                n_tests += kClusterSize;
+                uint32_t cand = ~miss & 0xFFFFu;  // bit 15-k: member step k
+                while (cand) {
+                    const uint32_t k = static_cast<uint32_t>(__builtin_clz(cand)) - 16u;
+                    cand &= ~(0x8000u >> k);
+                    examine_keyed(slots, idx_map, base + ((k + lane) & (kClusterSize - 1u)), p, key[r], kslot[r]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool hit = key[r] != ~0ull;
+        best[r] = hit ? __uint_as_float(static_cast<uint32_t>(key[r] >> 32)) : __builtin_inff();
+        best_i[r] = hit ? static_cast<int>(kslot[r]) : -1;
+        best_o[r] = static_cast<uint32_t>(key[r]);
     }
 }
 
@@ -582,18 +688,31 @@ DI uint32_t lane_rank(unsigned long long mask) {  // number of set bits of mask 
                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
-template <bool SHADE_LDS>
+template <bool SHADE_LDS, bool ACCEL>
 __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, PersistArgs g) {
+    // LDS: sphere list [g.n_pad float4] — the flat list, or (ACCEL) the clustered list's slots, then
+    // (ACCEL) the slots' original indices [g.n_pad u32] and the cluster bounds [a.n_clusters float4];
+    // then (SHADE_LDS) two float4 of shading record per sphere; then the accumulator entries of every
+    // wave of the workgroup (a wave allocates only from its own 64); then the tail pool:
+    // {parked, arrived, published, pad} + kTailPool records.
     extern __shared__ float4 lds_spheres[];
-    float4* lds_shade = lds_spheres + g.n_pad;  // SHADE_LDS: 2 x float4 per sphere
-    // accumulator entries of every wave of the workgroup (a wave allocates only from its own 64), then
-    // the tail pool: {parked, arrived, pad, pad} + kTailPool records
+    uint32_t* lds_cidx = reinterpret_cast<uint32_t*>(lds_spheres + g.n_pad);
+    float4* lds_cbounds = reinterpret_cast<float4*>(lds_cidx + (ACCEL ? g.n_pad : 0u));
+    float4* lds_shade = lds_cbounds + (ACCEL ? a.n_clusters : 0u);
     unsigned long long* lds_acc = reinterpret_cast<unsigned long long*>(lds_shade + (SHADE_LDS ? 2u * a.n : 0u));
     const uint32_t waves_in_group = blockDim.x / 64u;
     const uint32_t wave_in_group = threadIdx.x / 64u;
     uint32_t* lds_tail = reinterpret_cast<uint32_t*>(lds_acc + waves_in_group * (kWaveAccBytes / 8u));
     if (threadIdx.x < 4u) lds_tail[threadIdx.x] = 0u;
-    stage_spheres(a, lds_spheres, g.n_pad);
+    if (ACCEL) {
+        for (uint32_t i = threadIdx.x; i < g.n_pad; i += blockDim.x) {
+            lds_spheres[i] = a.cslots[i];
+            lds_cidx[i] = a.cidx[i];
+        }
+        for (uint32_t i = threadIdx.x; i < a.n_clusters; i += blockDim.x) lds_cbounds[i] = a.cbounds[i];
+    } else {
+        stage_spheres(a, lds_spheres, g.n_pad);
+    }
     if (SHADE_LDS) {
         const float4* src = reinterpret_cast<const float4*>(a.shade);
         for (uint32_t i = threadIdx.x; i < 2u * a.n; i += blockDim.x) lds_shade[i] = src[i];
@@ -618,7 +737,7 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
     // a wave parks at most kDonateMax paths, so that all donors fit the pool
     const uint32_t donate_max = waves_in_group > 1u ? (kTailPool / (waves_in_group - 1u) < kSparseMax
                                                             ? kTailPool / (waves_in_group - 1u) : kSparseMax) : 0u;
-    uint32_t n_paths = 0, n_segments = 0;
+    uint32_t n_paths = 0, n_segments = 0, n_tests = 0;
     [[maybe_unused]] uint32_t dbg_slow_trips = 0, dbg_cands = 0, dbg_iters = 0, dbg_sparse = 0;
     [[maybe_unused]] unsigned long long dbg_t_refill = 0, dbg_t_trace = 0, dbg_t_slow = 0, dbg_t_shade = 0;
     [[maybe_unused]] const unsigned long long dbg_c0 = DBG_STAMP();
@@ -769,15 +888,26 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
 
         // ---- trace ----------------------------------------------------------
         float best[kSlots];
-        int best_i[kSlots];
+        int best_i[kSlots];        // slot of the hit in the LDS list, -1: miss
+        uint32_t best_o[kSlots];   // its original sphere index
         uint32_t live_paths = 0u;
 #pragma unroll
         for (int r = 0; r < kSlots; ++r) live_paths += static_cast<uint32_t>(__popcll(__ballot(sl[r].active)));
         if (live_paths <= kSparseMax) {
-            trace_sparse<kSlots>(lds_spheres, g.n_pad, a.n, sl, best, best_i);
+            trace_sparse<kSlots>(lds_spheres, ACCEL ? lds_cidx : nullptr, g.n_pad, a.n, sl, best, best_i, best_o);
+#pragma unroll
+            for (int r = 0; r < kSlots; ++r)
+                if (sl[r].active) n_tests += ACCEL ? g.n_pad - g.n_pad / kClusterStride : a.n;
             DBG_ADD(dbg_sparse, lane == 0u ? 1u : 0u);
+        } else if (ACCEL) {
+            trace_clustered<kSlots>(lds_spheres, lds_cidx, lds_cbounds, a.n_clusters, sl, best, best_i, best_o, n_tests);
         } else {
             trace_slots<kSlots>(lds_spheres, g.n_pad, a.n, sl, best, best_i, dbg_slow_trips, dbg_cands, dbg_t_slow);
+#pragma unroll
+            for (int r = 0; r < kSlots; ++r) {
+                best_o[r] = static_cast<uint32_t>(best_i[r]);
+                if (sl[r].active) n_tests += a.n;
+            }
         }
         DBG_ADD(dbg_iters, lane == 0u ? 1u : 0u);
         [[maybe_unused]] const unsigned long long t2 = DBG_STAMP();
@@ -800,11 +930,11 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
                     const float4 geo = lds_spheres[best_i[r]];
                     ShadeRec m;
                     if (SHADE_LDS) {
-                        const float4 m0 = lds_shade[2 * best_i[r]], m1 = lds_shade[2 * best_i[r] + 1];
+                        const float4 m0 = lds_shade[2u * best_o[r]], m1 = lds_shade[2u * best_o[r] + 1u];
                         m.albedo[0] = m0.x; m.albedo[1] = m0.y; m.albedo[2] = m0.z; m.param = m0.w;
                         m.inv_r = m1.x; m.kind = __float_as_uint(m1.y);
                     } else {
-                        m = a.shade[best_i[r]];
+                        m = a.shade[best_o[r]];
                     }
                     if (!scatter(mk(geo.x, geo.y, geo.z), m, best[r], q.p)) {
                         finished = true;  // absorbed: radiance 0
@@ -842,13 +972,16 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
     }
 
     // one counter update per wave
+    unsigned long long tests64 = n_tests;
     for (int off = 32; off > 0; off >>= 1) {
         n_paths += __shfl_down(n_paths, off);
         n_segments += __shfl_down(n_segments, off);
+        tests64 += __shfl_down(tests64, off);
     }
     if (lane == 0u) {
         atomicAdd(&a.counters->paths, static_cast<unsigned long long>(n_paths));
         atomicAdd(&a.counters->segments, static_cast<unsigned long long>(n_segments));
+        atomicAdd(&a.counters->tests, tests64);
     }
 #ifdef RTIOW_DEBUG_COUNTERS
     // debug[0] wave-level slow-loop trips, [1] lane-level candidates, [2] wave iterations
@@ -922,21 +1055,27 @@ hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, in
         hipLaunchKernelGGL(path_pixel_kernel, dim3(tiles), dim3(256), lds, stream, a);
         return hipGetLastError();
     }
+    const bool accel = kernel == KERNEL_CLUSTERED;
     PersistArgs g{};
-    g.n_pad = (a.n + kBlockSph - 1u) / kBlockSph * kBlockSph;
+    // slots of the LDS sphere list: the flat list padded to whole candidate words, or the clustered one
+    g.n_pad = accel ? a.n_clusters * kClusterStride : (a.n + kBlockSph - 1u) / kBlockSph * kBlockSph;
     (void)max_take;  // scheduling is per sample now; the hint is accepted and ignored
     g.total_pix = a.local_rows * a.width;
     g.pool_pix = 2048u / a.spp;  // ~2048 samples per pool away from the tail
     g.pool_pix = g.pool_pix < 1u ? 1u : (g.pool_pix > 256u ? 256u : g.pool_pix);
-    // LDS per workgroup: the padded sphere list (16 B each); while the list is small, the
-    // shading records too (32 B each); 2 KiB of pixel accumulator entries per wave and the 7 KiB tail pool.
-    const size_t lds_geo = static_cast<size_t>(g.n_pad) * sizeof(float4);
-    const bool shade_lds = lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 24u * 1024u;
+    // LDS per workgroup: the sphere list (16 B per slot; clustered: + 4 B per slot of indices and
+    // 16 B per cluster bound); while the scene is small, the shading records too (32 B each);
+    // 2 KiB of pixel accumulator entries per wave and the 7 KiB tail pool.
+    const size_t lds_geo = static_cast<size_t>(g.n_pad) * sizeof(float4) +
+                           (accel ? static_cast<size_t>(g.n_pad) * 4u + static_cast<size_t>(a.n_clusters) * 16u : 0u);
+    const bool shade_lds = lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 28u * 1024u;
     const size_t lds_scene = lds_geo + (shade_lds ? static_cast<size_t>(a.n) * sizeof(ShadeRec) : 0u);
     // small scenes -> 256-thread groups; large ones -> 1024-thread groups so 16 waves share one copy
-    const uint32_t threads = lds_scene <= 24u * 1024u ? 256u : 1024u;
+    const uint32_t threads = lds_scene <= 28u * 1024u ? 256u : 1024u;
     const size_t lds = lds_scene + static_cast<size_t>(threads / 64u) * kWaveAccBytes + kTailBytes;
-    auto kernel_fn = shade_lds ? path_persistent_kernel<true> : path_persistent_kernel<false>;
+    void (*kernel_fn)(PathArgs, PersistArgs) =
+        accel ? (shade_lds ? path_persistent_kernel<true, true> : path_persistent_kernel<false, true>)
+              : (shade_lds ? path_persistent_kernel<true, false> : path_persistent_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return e;
