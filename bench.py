@@ -25,6 +25,8 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FLOPS_PER_TEST = 16             # oc 3, hb 5, cc 6, disc 2 (unit direction: a == 1)
 FLOPS_PER_SEGMENT_SHADE = 60
 
+KERNEL_NAMES = {0: "persistent_flat_list", 1: "pixel_per_lane", 2: "persistent_flat_list", 3: "persistent_clustered_list"}
+
 WORKLOADS = {
     # name: (scene, grid_half, width, height, spp, depth)
     "cover_1200x800_100spp": ("cover", 11, 1200, 800, 100, 50),
@@ -101,7 +103,8 @@ def main():
     ap.add_argument("--workload", default="cover_1200x800_100spp", choices=sorted(WORKLOADS))
     ap.add_argument("--chunk-spp", type=int, default=10)
     ap.add_argument("--row-block", type=int, default=4)
-    ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--kernel", type=int, default=0,
+                    help="0/2 persistent flat list (the north-star kernel), 3 persistent clustered list, 1 one lane per pixel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
@@ -196,39 +199,52 @@ def main():
         nominal = w * h * spp * depth
         value = nominal / (elapsed / args.steps) / 1e6
         n = len(sph)
-        # dominant kernel: the path-trace kernel of rank 0's tile (per launch)
-        flops = st.segments * (FLOPS_PER_TEST * n + FLOPS_PER_SEGMENT_SHADE)
+        # dominant kernel: the path-trace kernel of rank 0's tile (per launch); flops from the tests the
+        # kernel actually performed (flat list: segments * N; clustered list: bounds + members visited)
+        flops = st.sphere_tests * FLOPS_PER_TEST + st.segments * FLOPS_PER_SEGMENT_SHADE
         achieved = flops / (kernel_ms * 1e-3) / 1e12
         fb_bytes = st.bytes_written
         traffic = None
-        tpath = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "traffic_r*.json")) or [""])[-1]
+        tname = "traffic_r*c.json" if args.kernel == 3 else "traffic_r[0-9][0-9].json"
+        tpath = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", tname)) or [""])[-1]
         if world == 1 and tpath and os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("workload") == args.workload:
+            if tj.get("workload") == args.workload and tj.get("bench_kernel") == KERNEL_NAMES.get(args.kernel):
                 traffic = tj.get("hbm_bytes_per_launch")
         out = {
             "metric": "Mray/s (w*h*spp*depth / s), cover scene 1200x800", "value": value, "unit": "Mray/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": args.workload, "spheres": n, "width": w, "height": h, "spp": spp,
+            "config": {"workload": args.workload, "kernel": KERNEL_NAMES.get(args.kernel, str(args.kernel)), "spheres": n, "width": w, "height": h, "spp": spp,
                        "max_depth": depth, "chunk_spp": args.chunk_spp, "seed": 1,
                        "partition": (f"row-tiles block-cyclic x{args.row_block} over {world} GPUs + RCCL gather"
                                      if world > 1 else "single GPU"),
                        "segments_per_frame": int(segments), "segments_per_s": segments / (elapsed / args.steps),
-                       "sphere_tests_per_s": segments * n / (elapsed / args.steps),
+                       "sphere_tests_per_s": st.sphere_tests * (segments / max(1, st.segments)) / (elapsed / args.steps),
+                       "tests_per_segment": st.sphere_tests / max(1, st.segments),
                        "kernel_ms_rank0": kernel_ms, "kernel_ms_max": kernel_ms_max},
             "roofline": {
                 "bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": traffic,
                 "note": "fp32 vector-ALU bound (no dense contraction: MFMA unused by design); algorithmic "
-                        f"flops = segments*({FLOPS_PER_TEST}*N+{FLOPS_PER_SEGMENT_SHADE}), kernel time = HIP events "
-                        "on the launch stream over the timed steps",
+                        f"flops = tests*{FLOPS_PER_TEST} + segments*{FLOPS_PER_SEGMENT_SHADE} (flat list: tests = "
+                        "segments*N), kernel time = HIP events on the launch stream over the timed steps",
                 "hbm_write": {"achieved": fb_bytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": fb_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "bytes_per_launch": fb_bytes},
             },
         }
+        if world == 1:  # the other persistent kernel on the same frame, outside the timed region
+            other = 3 if args.kernel in (0, 2) else 2
+            oprm = V.make_params(w, h, spp=spp, max_depth=depth, seed=1, quantiser=V.RT_QUANT_BOOK, kernel=other)
+            oms = []
+            for _ in range(3):
+                ctx.render_device(cam, oprm, local.data_ptr(), w * 4, stream)
+                oms.append(ctx.stats().kernel_ms)
+            ost = ctx.stats()
+            out["config"]["other_kernel"] = {"kernel": KERNEL_NAMES[other], "kernel_ms": min(oms),
+                                             "tests_per_segment": ost.sphere_tests / max(1, ost.segments)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(V, sph, mat, cam, w, h, spp, depth, args.chunk_spp, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -34,16 +34,19 @@ for kind in ("fetch", "write", "sq", "lds"):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "")
         name = re.sub(r"^void ", "", name)
-        name = re.sub(r"[(<].*", "", name).split("::")[-1]
+        name = re.sub(r"\(.*", "", name)                       # drop the argument list, keep <template args>
+        name = name.split("::")[-1] if "<" not in name else name[name.rfind("::", 0, name.index("<")) + 2:]
+        name = name.replace(" ", "")
         agg[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
         if "path_persistent" in name:
-            pmc.setdefault("_dispatch", {"vgpr": r["VGPR_Count"], "sgpr": r["SGPR_Count"], "lds": r["LDS_Block_Size"],
+            pmc.setdefault("_dispatch_" + name, {"vgpr": r["VGPR_Count"], "sgpr": r["SGPR_Count"], "lds": r["LDS_Block_Size"],
                                          "scratch": r["Scratch_Size"], "grid": r["Grid_Size"], "wg": r["Workgroup_Size"]})
     for (name, ctr), vals in agg.items():
         pmc.setdefault(name, {})[ctr] = {"mean_per_launch": sum(vals) / len(vals), "launches": len(vals)}
 
 traffic = None
-pk = next((k for k in pmc if k.startswith("path_persistent")), None)
+want_accel = (bench_line or {}).get("config", {}).get("kernel") == "persistent_clustered_list"
+pk = next((k for k in pmc if k.startswith("path_persistent") and k.endswith(",true>" if want_accel else ",false>")), None)
 rk = next((k for k in pmc if k.startswith("resolve")), None)
 if pk and "FETCH_SIZE" in pmc[pk] and "WRITE_SIZE" in pmc[pk]:
     # MI355X_MICROARCH.md "HBM": counters are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B,
@@ -51,6 +54,7 @@ if pk and "FETCH_SIZE" in pmc[pk] and "WRITE_SIZE" in pmc[pk]:
     def bytes_of(k):
         return (2.0 * pmc[k]["FETCH_SIZE"]["mean_per_launch"] + pmc[k]["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
     traffic = {"workload": (bench_line or {}).get("config", {}).get("workload", "cover_1200x800_100spp"),
+               "bench_kernel": (bench_line or {}).get("config", {}).get("kernel", "persistent_flat_list"),
                "kernel": pk, "hbm_bytes_per_launch": bytes_of(pk),
                "fetch_kib_raw": pmc[pk]["FETCH_SIZE"]["mean_per_launch"], "write_kib_raw": pmc[pk]["WRITE_SIZE"]["mean_per_launch"],
                "resolve_kernel_hbm_bytes_per_launch": bytes_of(rk) if rk and "FETCH_SIZE" in pmc[rk] else None,

@@ -29,8 +29,9 @@ struct ShadeRec {
 };
 
 // Two-level sphere list of the clustered kernel (rtiow_clusters.cpp): clusters of kClusterSize
-// members, kClusterStride slots apart (the odd stride staggers the LDS banks of different clusters).
-constexpr uint32_t kClusterSize = 16, kClusterStride = 17;
+// members, kClusterStride slots apart.  With the lane-rotated member order of the kernel, a stride of
+// 16 slots (256 B = one LDS bank row) makes the bank of a read depend on the lane only: conflict-free.
+constexpr uint32_t kClusterSize = 16, kClusterStride = 16;
 
 struct PathArgs {
     const float4* spheres;       // n x {cx,cy,cz,radius} as uploaded (RtSphere)

@@ -897,7 +897,7 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
             trace_sparse<kSlots>(lds_spheres, ACCEL ? lds_cidx : nullptr, g.n_pad, a.n, sl, best, best_i, best_o);
 #pragma unroll
             for (int r = 0; r < kSlots; ++r)
-                if (sl[r].active) n_tests += ACCEL ? g.n_pad - g.n_pad / kClusterStride : a.n;
+                if (sl[r].active) n_tests += ACCEL ? g.n_pad : a.n;
             DBG_ADD(dbg_sparse, lane == 0u ? 1u : 0u);
         } else if (ACCEL) {
             trace_clustered<kSlots>(lds_spheres, lds_cidx, lds_cbounds, a.n_clusters, sl, best, best_i, best_o, n_tests);
