@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RTIOW_ABI_VERSION 1
+#define RTIOW_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------ */
 enum {
@@ -113,8 +113,15 @@ typedef struct RtParams {
     uint32_t row_block;
     uint32_t tile_rank;
     uint32_t tile_count;
-    uint32_t kernel;     /* 0 = default; other values select kernel variants (rtiow_amd
-                            tuning/ablation only — results are identical by contract) */
+    uint32_t kernel;     /* 0 = default (persistent, flat list); 1 one lane per pixel; 2 persistent,
+                            flat list; 3 persistent, clustered list.  Frames are identical by contract. */
+    /* Progressive accumulation, the frame loop of RTCHAP06/main.cpp:304-360 with a running
+     * average: with accumulate != 0 this dispatch adds samples sample_offset .. sample_offset+spp-1
+     * of every pixel to accumulators the context keeps (reset when sample_offset == 0) and writes
+     * the average of all sample_offset+spp samples so far.  k dispatches of spp samples give, bit
+     * for bit, the frame of one dispatch of k*spp samples.  sample_offset + spp <= 65536. */
+    uint32_t sample_offset;
+    uint32_t accumulate;
 } RtParams;
 
 typedef struct RtStats {

@@ -156,6 +156,31 @@ def test_path_tiles_reassemble_to_the_single_gpu_frame(gpu_ctx, oracle, kernel):
         assert np.array_equal(frame, full), (count, block)
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_progressive_accumulation_equals_one_big_dispatch(gpu_ctx, oracle, kernel):
+    """The frame loop with a running average (RTCHAP06/main.cpp:304-360 re-dispatches every frame):
+    k dispatches of spp samples each == one dispatch of k*spp samples, bit for bit, and every
+    intermediate average is the oracle's frame at that sample count."""
+    w, h = 61, 37
+    sph, mat, cam = _case(oracle, "cover11", w, h)
+    gpu_ctx.set_scene(sph, mat)
+    done = 0
+    for spp in (3, 1, 4, 2):
+        prm = V.make_params(w, h, spp=spp, max_depth=50, seed=4, kernel=kernel, sample_offset=done, accumulate=1)
+        got = gpu_ctx.render(cam, prm)
+        done += spp
+        want, _ = oracle.render(sph, mat, cam, V.make_params(w, h, spp=done, max_depth=50, seed=4))
+        assert np.array_equal(got, want), done
+    # a dispatch that does not continue where the accumulators stand is refused
+    with pytest.raises(V.RtError) as e:
+        gpu_ctx.render(cam, V.make_params(w, h, spp=2, seed=4, kernel=kernel, sample_offset=done + 5, accumulate=1))
+    assert e.value.code == V.RT_ERR_STATE
+    # restarting at offset 0 resets them
+    again = gpu_ctx.render(cam, V.make_params(w, h, spp=3, max_depth=50, seed=4, kernel=kernel, accumulate=1))
+    want3, _ = oracle.render(sph, mat, cam, V.make_params(w, h, spp=3, max_depth=50, seed=4))
+    assert np.array_equal(again, want3)
+
+
 def test_path_seed_and_determinism(gpu_ctx, oracle):
     sph, mat, cam = _case(oracle, "three", 64, 36)
     gpu_ctx.set_scene(sph, mat)

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     lib = V.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.rtAbiVersion() == 1
+    assert lib.rtAbiVersion() == 2
 
 
 def test_struct_layouts_match_header():
@@ -27,7 +27,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(V.RtSphere) == 16
     assert C.sizeof(V.RtMaterial) == 32
     assert C.sizeof(V.RtCamera) == 88
-    assert C.sizeof(V.RtParams) == 48
+    assert C.sizeof(V.RtParams) == 56
 
 
 def test_ubo_formula_matches_reference_main_cpp(oracle):

@@ -51,7 +51,7 @@ class RtCamera(C.Structure):
 class RtParams(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in
                 ("width", "height", "spp", "max_depth", "seed", "mode", "quantiser", "chunk_spp",
-                 "row_block", "tile_rank", "tile_count", "kernel")]
+                 "row_block", "tile_rank", "tile_count", "kernel", "sample_offset", "accumulate")]
 
 
 class RtStats(C.Structure):
@@ -113,7 +113,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.rtAbiVersion() != 1:
+    if lib.rtAbiVersion() != 2:
         raise ImportError("librtiow_hip.so has an unexpected ABI version")
     if path == LIB_PATH:
         _lib = lib
@@ -187,9 +187,9 @@ def _check(ctx, code: int, where: str) -> None:
 
 def make_params(width, height, spp=1, max_depth=50, seed=1, mode=RT_MODE_PATH,
                 quantiser=RT_QUANT_BOOK, chunk_spp=0, row_block=0, tile_rank=0, tile_count=0,
-                kernel=KERNEL_DEFAULT) -> RtParams:
+                kernel=KERNEL_DEFAULT, sample_offset=0, accumulate=0) -> RtParams:
     return RtParams(width, height, spp, max_depth, seed, mode, quantiser, chunk_spp, row_block,
-                    tile_rank, tile_count, kernel)
+                    tile_rank, tile_count, kernel, sample_offset, accumulate)
 
 
 class Context:

@@ -30,6 +30,10 @@ struct RtContext {
     rtiow::Counters* h_counters = nullptr;  // pinned
     uint32_t* d_frame = nullptr;            // staging framebuffer for host destinations
     size_t frame_bytes = 0;
+    unsigned long long* d_accum = nullptr;  // progressive accumulation: 4 x u64 per pixel of the tile
+    size_t accum_bytes = 0;
+    uint64_t accum_key = 0;                 // which frame the accumulators belong to
+    uint32_t accum_samples = 0;             // samples accumulated so far
     bool have_timing = false;
     hipStream_t last_stream = nullptr;
     RtStats stats{};
@@ -129,6 +133,7 @@ int rtDestroy(RtContext* ctx) {
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+    if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -264,6 +269,21 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         a.max_depth = prm->max_depth;
         a.seed = prm->seed;
         a.quantiser = prm->quantiser;
+        a.sample_offset = prm->accumulate ? prm->sample_offset : 0u;
+        a.accum = nullptr;
+        if (prm->accumulate) {
+            // the accumulators belong to one (size, tile) frame; a new frame starts at sample_offset 0
+            const uint64_t key = (uint64_t(W) << 40) ^ (uint64_t(H) << 20) ^ (uint64_t(rblock) << 12) ^
+                                 (uint64_t(prm->tile_rank) << 6) ^ uint64_t(tcount);
+            if (prm->sample_offset != 0u && (key != ctx->accum_key || prm->sample_offset != ctx->accum_samples))
+                return fail(ctx, RT_ERR_STATE, "rtRender: accumulate continues a different frame or sample count");
+            int rc = ensure_bytes(ctx, reinterpret_cast<void**>(&ctx->d_accum), &ctx->accum_bytes,
+                                  size_t(rows) * W * 4 * sizeof(unsigned long long));
+            if (rc != RT_OK) return rc;
+            a.accum = ctx->d_accum;
+            ctx->accum_key = key;
+            ctx->accum_samples = prm->sample_offset + prm->spp;
+        }
         a.inv_wm1 = 1.0f / static_cast<float>(W - 1);
         a.inv_hm1 = 1.0f / static_cast<float>(H - 1);
         a.row_block = rblock;
@@ -306,6 +326,8 @@ int rtRender(RtContext* ctx, const RtCamera* cam, const RtParams* params, void* 
         return fail(ctx, RT_ERR_INVALID, "rtRender: PATH mode needs width,height >= 2");
     if (params->spp == 0 || params->spp > 65536)
         return fail(ctx, RT_ERR_INVALID, "rtRender: spp must be 1..65536");
+    if (params->accumulate && (params->sample_offset > 65536u - params->spp))
+        return fail(ctx, RT_ERR_INVALID, "rtRender: sample_offset + spp must not exceed 65536");
     if (params->quantiser > RT_QUANT_BOOK) return fail(ctx, RT_ERR_INVALID, "rtRender: unknown quantiser");
     return render_common(ctx, false, nullptr, cam, params, dst, dst_pitch, dst_is_device, stream);
 }

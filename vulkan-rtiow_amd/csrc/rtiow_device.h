@@ -44,6 +44,8 @@ struct PathArgs {
     RtCamera cam;
     uint32_t width, height;      // full image
     uint32_t spp, max_depth, seed, quantiser;
+    uint32_t sample_offset;      // first sample index of this dispatch (progressive accumulation)
+    unsigned long long* accum;   // progressive: local_pixels x 4 u64 {r,g,b,-} kept by the context, else null
     float inv_wm1, inv_hm1;      // 1/(width-1), 1/(height-1), rounded once on the host
     uint32_t row_block, tile_rank, tile_count;
     uint32_t local_rows;         // rows this call renders

@@ -66,6 +66,25 @@ DI uint32_t resolve_pixel(unsigned long long sr, unsigned long long sg, unsigned
     return pack_rgb(quant_unorm8(r), quant_unorm8(g), quant_unorm8(b));
 }
 
+// Turns a pixel's sums of THIS dispatch into its colour.  Progressive accumulation: the context's
+// accumulators hold the sums of the samples before a.sample_offset; the pixel is owned by exactly one
+// lane per dispatch, so a plain read-modify-write suffices.
+DI uint32_t close_pixel(const PathArgs& a, uint32_t local_pix, unsigned long long sr, unsigned long long sg,
+                        unsigned long long sb) {
+    if (a.accum != nullptr) {
+        unsigned long long* acc = a.accum + static_cast<size_t>(local_pix) * 4u;
+        if (a.sample_offset != 0u) {
+            sr += acc[0];
+            sg += acc[1];
+            sb += acc[2];
+        }
+        acc[0] = sr;
+        acc[1] = sg;
+        acc[2] = sb;
+    }
+    return resolve_pixel(sr, sg, sb, a.sample_offset + a.spp, a.quantiser);
+}
+
 DI uint32_t tile_global_row(uint32_t lr, uint32_t row_block, uint32_t rank, uint32_t count) {
     if (count <= 1) return lr;
     return ((lr / row_block) * count + rank) * row_block + lr % row_block;
@@ -336,7 +355,7 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
         unsigned long long sr = 0ull, sg = 0ull, sb = 0ull;
         for (uint32_t s = 0; s < a.spp; ++s) {
             Path p;
-            camera_path(a, i, j, s, p);
+            camera_path(a, i, j, a.sample_offset + s, p);
             ++n_paths;
             for (uint32_t depth = 0; depth < a.max_depth; ++depth) {
                 ++n_segments;
@@ -353,7 +372,7 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
                 if (!scatter(mk(g.x, g.y, g.z), a.shade[idx], dist, p)) break;
             }
         }
-        a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = resolve_pixel(sr, sg, sb, a.spp, a.quantiser);
+        a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = close_pixel(a, lr * a.width + i, sr, sg, sb);
     }
     atomicAdd(&blk_paths, n_paths);
     atomicAdd(&blk_segments, n_segments);
@@ -800,7 +819,7 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
             if (got_sample) {  // start the sample
                 const uint32_t lr = q.pix / a.width, i = q.pix - lr * a.width;
                 const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
-                camera_path(a, i, j, my_s, q.p);
+                camera_path(a, i, j, a.sample_offset + my_s, q.p);
                 q.depth = 0u;
                 q.active = true;
                 ++n_paths;
@@ -955,7 +974,7 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
                     completed = true;
                     const uint32_t lr = q.pix / a.width, i = q.pix - lr * a.width;
                     a.dst[static_cast<size_t>(lr) * a.dst_stride + i] =
-                        resolve_pixel(acc[0], acc[1], acc[2], a.spp, a.quantiser);
+                        close_pixel(a, q.pix, acc[0], acc[1], acc[2]);
                 }
             }
             unsigned long long done_mask = __ballot(completed);

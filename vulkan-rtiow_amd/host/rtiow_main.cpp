@@ -3,10 +3,19 @@
 // (main.cpp:313-325) and, instead of presenting to a swapchain (main.cpp:326-357)
 // or taking a JPEG screenshot (Vulkan.cpp:625-766), writes a lossless PPM.
 //
-//   rtiow_main --scene cover|three|ch05|ch06 [--width W --height H --spp S --depth D
-//              --seed N --chunk C --frames F --out file.ppm --device G]
+//   rtiow_main --scene cover|cover4096|three|ch05|ch06|file [--file scene.txt] [--width W --height H
+//              --spp S --depth D --seed N --kernel K --frames F --progressive 0|1 --out file.ppm
+//              --device G]
+//
+// --progressive 1 makes the F frames a running average (RtParams.accumulate): frame f adds spp new
+// samples to the picture.  A scene file (parameters instead of the compile-time
+// constants of main.cpp:15-16,101-102,116-120) is plain text, one item per line, '#' comments:
+//   camera  fx fy fz  ax ay az  ux uy uz  vfov aperture focus
+//   sphere  cx cy cz radius  lambertian r g b | metal r g b fuzz | dielectric ior
 #include <chrono>
 #include <cstdio>
+#include <fstream>
+#include <sstream>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -22,9 +31,53 @@ int die(RtContext* ctx, const char* what, int rc) {
 }
 }  // namespace
 
+// scene file -> arrays + camera; returns false with a message on a malformed line
+static bool load_scene_file(const std::string& path, float aspect, std::vector<RtSphere>& sph,
+                            std::vector<RtMaterial>& mat, RtCamera& cam, bool& have_cam) {
+    std::ifstream in(path);
+    if (!in) { std::fprintf(stderr, "cannot open %s\n", path.c_str()); return false; }
+    std::string line;
+    int ln = 0;
+    have_cam = false;
+    while (std::getline(in, line)) {
+        ++ln;
+        const size_t hash = line.find('#');
+        if (hash != std::string::npos) line.resize(hash);
+        std::istringstream ls(line);
+        std::string what;
+        if (!(ls >> what)) continue;
+        if (what == "camera") {
+            float f[3], a[3], u[3], vfov, aperture, focus;
+            if (!(ls >> f[0] >> f[1] >> f[2] >> a[0] >> a[1] >> a[2] >> u[0] >> u[1] >> u[2] >> vfov >> aperture >> focus) ||
+                rtMakeCamera(f, a, u, vfov, aspect, aperture, focus, &cam) != RT_OK) {
+                std::fprintf(stderr, "%s:%d: bad camera\n", path.c_str(), ln);
+                return false;
+            }
+            have_cam = true;
+        } else if (what == "sphere") {
+            RtSphere s{};
+            RtMaterial m{};
+            std::string kind;
+            if (!(ls >> s.cx >> s.cy >> s.cz >> s.radius >> kind)) { std::fprintf(stderr, "%s:%d: bad sphere\n", path.c_str(), ln); return false; }
+            bool ok = true;
+            if (kind == "lambertian") { m.kind = RT_MAT_LAMBERTIAN; ok = bool(ls >> m.albedo[0] >> m.albedo[1] >> m.albedo[2]); }
+            else if (kind == "metal") { m.kind = RT_MAT_METAL; ok = bool(ls >> m.albedo[0] >> m.albedo[1] >> m.albedo[2] >> m.fuzz); }
+            else if (kind == "dielectric") { m.kind = RT_MAT_DIELECTRIC; m.albedo[0] = m.albedo[1] = m.albedo[2] = 1.0f; ok = bool(ls >> m.ior); }
+            else ok = false;
+            if (!ok) { std::fprintf(stderr, "%s:%d: bad material\n", path.c_str(), ln); return false; }
+            sph.push_back(s);
+            mat.push_back(m);
+        } else {
+            std::fprintf(stderr, "%s:%d: unknown item '%s'\n", path.c_str(), ln, what.c_str());
+            return false;
+        }
+    }
+    return !sph.empty();
+}
+
 int main(int argc, char** argv) {
-    std::string scene = "cover", out = "frame.ppm";
-    uint32_t width = 1200, height = 800, spp = 100, depth = 50, seed = 1, chunk = 10, frames = 1;
+    std::string scene = "cover", out = "frame.ppm", file;
+    uint32_t width = 1200, height = 800, spp = 100, depth = 50, seed = 1, kernel = 0, frames = 1, progressive = 0;
     int device = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
         const std::string k = argv[i];
@@ -36,7 +89,9 @@ int main(int argc, char** argv) {
         else if (k == "--spp") spp = std::strtoul(v, nullptr, 10);
         else if (k == "--depth") depth = std::strtoul(v, nullptr, 10);
         else if (k == "--seed") seed = std::strtoul(v, nullptr, 10);
-        else if (k == "--chunk") chunk = std::strtoul(v, nullptr, 10);
+        else if (k == "--kernel") kernel = std::strtoul(v, nullptr, 10);
+        else if (k == "--progressive") progressive = std::strtoul(v, nullptr, 10);
+        else if (k == "--file") file = v;
         else if (k == "--frames") frames = std::strtoul(v, nullptr, 10);
         else if (k == "--device") device = std::atoi(v);
         else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
@@ -48,7 +103,7 @@ int main(int argc, char** argv) {
 
     RtParams prm{};
     prm.width = width; prm.height = height; prm.spp = spp; prm.max_depth = depth; prm.seed = seed;
-    prm.chunk_spp = chunk; prm.quantiser = RT_QUANT_BOOK; prm.mode = RT_MODE_PATH;
+    prm.kernel = kernel; prm.quantiser = RT_QUANT_BOOK; prm.mode = RT_MODE_PATH;
     RtCamera cam{};
     RtUbo5 ubo{};
     rtUboFromImage(width, height, &ubo);
@@ -58,7 +113,15 @@ int main(int argc, char** argv) {
         std::vector<RtSphere> sph(5000);
         std::vector<RtMaterial> mat(5000);
         uint32_t n = 0;
-        if (scene == "three") {
+        if (scene == "file") {
+            sph.clear();
+            mat.clear();
+            bool have_cam = false;
+            if (!load_scene_file(file, float(width) / float(height), sph, mat, cam, have_cam)) { rtDestroy(ctx); return 2; }
+            if (!have_cam) rtCameraFromUbo(&ubo, &cam);
+            n = static_cast<uint32_t>(sph.size());
+            rc = RT_OK;
+        } else if (scene == "three") {
             rc = rtMakeThreeSphereScene(1, sph.data(), mat.data(), 5000, &n);
             rtCameraFromUbo(&ubo, &cam);
         } else {
@@ -75,6 +138,10 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> frame(size_t(width) * height * 4);
     for (uint32_t f = 0; f < frames; ++f) {  // the frame loop of main.cpp:304-360
         const auto t0 = std::chrono::steady_clock::now();
+        if (progressive && prm.mode == RT_MODE_PATH) {  // running average over the frames so far
+            prm.accumulate = 1;
+            prm.sample_offset = f * spp;
+        }
         rc = rtRender(ctx, &cam, &prm, frame.data(), size_t(width) * 4, 0, nullptr);
         if (rc != RT_OK) return die(ctx, "rtRender", rc);
         const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
