@@ -105,6 +105,11 @@ def main():
     ap.add_argument("--row-block", type=int, default=4)
     ap.add_argument("--kernel", type=int, default=0,
                     help="0/2 persistent flat list (the north-star kernel), 3 persistent clustered list, 1 one lane per pixel")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frames rendered concurrently on separate contexts/streams, as the reference keeps one "
+                         "compute fence per swapchain image (RTCHAP06/main.cpp:94-98,313-316); 0 = auto: 1 on one "
+                         "GPU (clean per-kernel roofline), 2 on several (a frame's tail of long paths and its "
+                         "gather overlap the next frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
@@ -140,26 +145,35 @@ def main():
 
     scene, grid_half, w, h, spp, depth = WORKLOADS[args.workload]
     sph, mat, cam = build_scene(V, scene, grid_half, w, h)
-    ctx = V.Context(local_rank)
-    ctx.set_scene(sph, mat)
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (1 if world == 1 else 2)
     prm = V.make_params(w, h, spp=spp, max_depth=depth, seed=1, chunk_spp=args.chunk_spp,
                         quantiser=V.RT_QUANT_BOOK, row_block=args.row_block if world > 1 else 0,
                         tile_rank=rank if world > 1 else 0, tile_count=world if world > 1 else 0,
                         kernel=args.kernel)
     rows = V.tile_row_count(h, prm.row_block, prm.tile_rank, prm.tile_count)
-    local = torch.zeros((rows, w), dtype=torch.int32, device=dev)
-    # a real (non-null) torch stream: the kernels, the timing events and the RCCL gather are all
-    # ordered on it (a NULL handle would mean "the context's own stream" to the C ABI)
-    tstream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(tstream)
-    stream = tstream.cuda_stream
-    assert stream != 0
+    # One context + one real (non-null) torch stream + one tile buffer per frame in flight: the kernels,
+    # the timing events and the RCCL gather of a frame are all ordered on its stream (a NULL handle
+    # would mean "the context's own stream" to the C ABI).
+    ctxs, streams, locals_ = [], [], []
+    for _ in range(F):
+        c = V.Context(local_rank)
+        c.set_scene(sph, mat)
+        ctxs.append(c)
+        streams.append(torch.cuda.Stream(device=dev))
+        locals_.append(torch.zeros((rows, w), dtype=torch.int32, device=dev))
+    ctx = ctxs[0]
 
-    def step():
-        ctx.render_device(cam, prm, local.data_ptr(), w * 4, stream)
-        if world > 1:
-            return D.gather_frame(local, h, prm.row_block, rank, world)
-        return local
+    def step(k, events=None):
+        i = k % F
+        with torch.cuda.stream(streams[i]):
+            if events is not None:
+                events[0].record()              # same stream the kernels are launched on
+            ctxs[i].render_device(cam, prm, locals_[i].data_ptr(), w * 4, streams[i].cuda_stream)
+            if events is not None:
+                events[1].record()
+            if world > 1:
+                return D.gather_frame(locals_[i], h, prm.row_block, rank, world)
+            return locals_[i]
 
     def fence():
         torch.cuda.synchronize()
@@ -167,17 +181,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     fence()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     frame = None
     for k in range(args.steps):
-        ev[k][0].record()                       # same stream the kernels are launched on
-        ctx.render_device(cam, prm, local.data_ptr(), w * 4, stream)
-        ev[k][1].record()
-        frame = D.gather_frame(local, h, prm.row_block, rank, world) if world > 1 else local
+        frame = step(k, ev[k])
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
@@ -220,6 +231,7 @@ def main():
                        "max_depth": depth, "chunk_spp": args.chunk_spp, "seed": 1,
                        "partition": (f"row-tiles block-cyclic x{args.row_block} over {world} GPUs + RCCL gather"
                                      if world > 1 else "single GPU"),
+                       "frames_in_flight": F,
                        "segments_per_frame": int(segments), "segments_per_s": segments / (elapsed / args.steps),
                        "sphere_tests_per_s": st.sphere_tests * (segments / max(1, st.segments)) / (elapsed / args.steps),
                        "tests_per_segment": st.sphere_tests / max(1, st.segments),
@@ -235,12 +247,29 @@ def main():
                               "bytes_per_launch": fb_bytes},
             },
         }
+        if world == 1 and F == 1:  # throughput of the same loop with two frames in flight (not `value`)
+            c2 = V.Context(local_rank)
+            c2.set_scene(sph, mat)
+            s2, b2 = torch.cuda.Stream(device=dev), torch.zeros_like(locals_[0])
+            pair = [(ctx, streams[0], locals_[0]), (c2, s2, b2)]
+            for k in range(2):
+                pair[k][0].render_device(cam, prm, pair[k][2].data_ptr(), w * 4, pair[k][1].cuda_stream)
+            torch.cuda.synchronize()
+            n2 = max(4, args.steps)
+            t2 = time.perf_counter()
+            for k in range(n2):
+                c_, s_, b_ = pair[k % 2]
+                c_.render_device(cam, prm, b_.data_ptr(), w * 4, s_.cuda_stream)
+            torch.cuda.synchronize()
+            ms2 = (time.perf_counter() - t2) / n2 * 1e3
+            out["config"]["two_frames_in_flight"] = {"ms_per_step": ms2, "value": nominal / (ms2 * 1e-3) / 1e6}
+            c2.close()
         if world == 1:  # the other persistent kernel on the same frame, outside the timed region
             other = 3 if args.kernel in (0, 2) else 2
             oprm = V.make_params(w, h, spp=spp, max_depth=depth, seed=1, quantiser=V.RT_QUANT_BOOK, kernel=other)
             oms = []
             for _ in range(3):
-                ctx.render_device(cam, oprm, local.data_ptr(), w * 4, stream)
+                ctx.render_device(cam, oprm, locals_[0].data_ptr(), w * 4, streams[0].cuda_stream)
                 oms.append(ctx.stats().kernel_ms)
             ost = ctx.stats()
             out["config"]["other_kernel"] = {"kernel": KERNEL_NAMES[other], "kernel_ms": min(oms),
@@ -251,7 +280,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for c in ctxs:
+        c.close()
 
 
 if __name__ == "__main__":
