@@ -119,6 +119,7 @@ def test_path_golden_crcs_on_gpu(gpu_ctx, oracle, kernel):
     ("cover11", 96, 64, 9, 5, 2, V.RT_QUANT_BOOK),           # depth exhaustion (black paths)
     ("cover32", 64, 40, 2, 50, 1, V.RT_QUANT_BOOK),          # ~4000 spheres: BASELINE config 5 scene
     ("cover3", 17, 9, 3, 50, 0, V.RT_QUANT_BOOK),            # image smaller than one tile
+    ("cover39", 40, 24, 1, 50, 0, V.RT_QUANT_BOOK),          # ~6000 spheres: the largest list LDS holds
 ])
 def test_path_bit_exact_vs_oracle(gpu_ctx, oracle, kernel, scene, w, h, spp, depth, chunk, quant):
     sph, mat, cam = _case(oracle, scene, w, h)

@@ -146,8 +146,9 @@ int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materi
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rtSetScene: ctx is null");
     if (!spheres || !materials || n_spheres == 0)
         return fail(ctx, RT_ERR_INVALID, "rtSetScene: empty scene or null arrays");
-    // sphere list {cx,cy,cz,r*r} must fit the 160 KiB LDS of a gfx950 CU with room to spare
-    if (n_spheres > 8192) return fail(ctx, RT_ERR_INVALID, "rtSetScene: more than 8192 spheres");
+    // the sphere list (16 B per sphere; clustered: 20 B per slot) must fit the 160 KiB LDS of a
+    // gfx950 CU beside the accumulator entries of at least 8 waves
+    if (n_spheres > 6144) return fail(ctx, RT_ERR_INVALID, "rtSetScene: more than 6144 spheres");
     for (uint32_t i = 0; i < n_spheres; ++i) {
         if (materials[i].kind > RT_MAT_DIELECTRIC)
             return fail(ctx, RT_ERR_INVALID, "rtSetScene: unknown material kind");

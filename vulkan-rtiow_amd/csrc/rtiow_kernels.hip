@@ -109,6 +109,14 @@ __global__ __launch_bounds__(256) void ch_kernel(ChArgs a) {
     const uint32_t tiles_x = (a.width + 15u) / 16u;
     const uint32_t gx = (blockIdx.x % tiles_x) * 16u + (threadIdx.x & 15u);
     const uint32_t gy = (blockIdx.x / tiles_x) * 16u + (threadIdx.x >> 4);
+    // u depends on the column only and v on the row only (raytrace06.comp:57-58): 32 IEEE divisions per
+    // 16x16 tile instead of 512, shared through LDS; the quotients are the per-pixel ones, bit for bit
+    __shared__ float uv[32];
+    if (threadIdx.x < 16u)
+        uv[threadIdx.x] = static_cast<float>((blockIdx.x % tiles_x) * 16u + threadIdx.x) / (a.ubo.imageWidth - 1);
+    else if (threadIdx.x < 32u)
+        uv[threadIdx.x] = static_cast<float>((blockIdx.x / tiles_x) * 16u + (threadIdx.x - 16u)) / (a.ubo.imageHeight - 1);
+    __syncthreads();
     if (gx >= a.width || gy >= a.height) return;
 
     // raytrace06.comp:53-61
@@ -119,8 +127,8 @@ __global__ __launch_bounds__(256) void ch_kernel(ChArgs a) {
     llc.x = ((origin.x - horizontal.x / 2) - vertical.x / 2) - 0.0f;
     llc.y = ((origin.y - horizontal.y / 2) - vertical.y / 2) - 0.0f;
     llc.z = ((origin.z - horizontal.z / 2) - vertical.z / 2) - a.ubo.focalLength;
-    const float u = static_cast<float>(gx) / (a.ubo.imageWidth - 1);
-    const float v = static_cast<float>(gy) / (a.ubo.imageHeight - 1);
+    const float u = uv[threadIdx.x & 15u];
+    const float v = uv[16u + (threadIdx.x >> 4)];
     f3 dir;
     dir.x = ((llc.x + horizontal.x * u) + vertical.x * v) - origin.x;
     dir.y = ((llc.y + horizontal.y * u) + vertical.y * v) - origin.y;
@@ -1090,8 +1098,12 @@ hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, in
     const bool shade_lds = lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 28u * 1024u;
     const size_t lds_scene = lds_geo + (shade_lds ? static_cast<size_t>(a.n) * sizeof(ShadeRec) : 0u);
     // small scenes -> 256-thread groups; large ones -> 1024-thread groups so 16 waves share one copy
-    const uint32_t threads = lds_scene <= 28u * 1024u ? 256u : 1024u;
+    // (a very large list leaves room for 8 waves' accumulators only: 512 threads)
+    uint32_t threads = lds_scene <= 28u * 1024u ? 256u : 1024u;
+    constexpr size_t kLdsPerCu = 160u * 1024u;
+    if (lds_scene + static_cast<size_t>(threads / 64u) * kWaveAccBytes + kTailBytes > kLdsPerCu) threads = 512u;
     const size_t lds = lds_scene + static_cast<size_t>(threads / 64u) * kWaveAccBytes + kTailBytes;
+    if (lds > kLdsPerCu) return hipErrorInvalidValue;  // rtSetScene's sphere limit keeps this from happening
     void (*kernel_fn)(PathArgs, PersistArgs) =
         accel ? (shade_lds ? path_persistent_kernel<true, true> : path_persistent_kernel<false, true>)
               : (shade_lds ? path_persistent_kernel<true, false> : path_persistent_kernel<false, false>);
