@@ -113,8 +113,9 @@ typedef struct RtParams {
     uint32_t row_block;
     uint32_t tile_rank;
     uint32_t tile_count;
-    uint32_t kernel;     /* 0 = default (persistent, flat list); 1 one lane per pixel; 2 persistent,
-                            flat list; 3 persistent, clustered list.  Frames are identical by contract. */
+    uint32_t kernel;     /* 0 = default (persistent; flat list up to 1024 spheres, clustered beyond);
+                            1 one lane per pixel; 2 persistent, flat list; 3 persistent, clustered
+                            list.  Frames are identical by contract. */
     /* Progressive accumulation, the frame loop of RTCHAP06/main.cpp:304-360 with a running
      * average: with accumulate != 0 this dispatch adds samples sample_offset .. sample_offset+spp-1
      * of every pixel to accumulators the context keeps (reset when sample_offset == 0) and writes

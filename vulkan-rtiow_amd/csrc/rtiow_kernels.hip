@@ -1082,7 +1082,9 @@ hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, in
         hipLaunchKernelGGL(path_pixel_kernel, dim3(tiles), dim3(256), lds, stream, a);
         return hipGetLastError();
     }
-    const bool accel = kernel == KERNEL_CLUSTERED;
+    // default: the flat list (the north-star kernel) for scenes up to 1024 spheres, the clustered one
+    // beyond (2.8x faster at 4096 spheres; frames are byte-identical either way)
+    const bool accel = kernel == KERNEL_CLUSTERED || (kernel == KERNEL_DEFAULT && a.n > 1024u);
     PersistArgs g{};
     // slots of the LDS sphere list: the flat list padded to whole candidate words, or the clustered one
     g.n_pad = accel ? a.n_clusters * kClusterStride : (a.n + kBlockSph - 1u) / kBlockSph * kBlockSph;
