@@ -92,9 +92,12 @@ def test_config5_scene_4096_spheres_3840x2160(gpu_ctx, oracle):
     assert 4000 <= len(sph) <= 4100
     gpu_ctx.set_scene(sph, mat)
     base = V.make_params(w, h, spp=2, max_depth=50, seed=1)
-    full = gpu_ctx.render(cam, base)
+    full = gpu_ctx.render(cam, base)           # default kernel: the clustered list beyond 1024 spheres
     st = gpu_ctx.stats()
-    assert st.paths == w * h * 2 and st.sphere_tests == st.segments * len(sph)
+    assert st.paths == w * h * 2 and st.sphere_tests < st.segments * len(sph) // 4
+    flat = gpu_ctx.render(cam, V.make_params(w, h, spp=2, max_depth=50, seed=1, kernel=V.KERNEL_PERSISTENT))
+    sf = gpu_ctx.stats()
+    assert np.array_equal(flat, full) and sf.segments == st.segments and sf.sphere_tests == sf.segments * len(sph)
     want, _ = _oracle_rows(oracle, sph, mat, cam, base, 240)
     assert np.array_equal(full[::240], want)
     again = gpu_ctx.render(cam, base)
