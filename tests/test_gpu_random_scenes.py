@@ -1,0 +1,53 @@
+"""GPU (-m gpu): randomized scenes (sizes, scales, materials, hollow spheres, cameras inside and far
+outside the scene, apertures) through all three PATH kernels against the oracle, bit for bit."""
+import numpy as np
+import pytest
+
+import vulkan_rtiow_amd as V
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_scene(rng, n, scale):
+    sph = np.zeros(n, V.SPHERE_DTYPE)
+    mat = np.zeros(n, V.MATERIAL_DTYPE)
+    sph["cx"] = rng.uniform(-1, 1, n) * scale
+    sph["cy"] = rng.uniform(-0.3, 0.3, n) * scale
+    sph["cz"] = rng.uniform(-1, 1, n) * scale
+    sph["radius"] = rng.uniform(0.02, 0.12, n) * scale * rng.choice([1.0, 1.0, 1.0, 3.0], n)
+    kinds = rng.choice([0, 1, 2], n, p=[0.6, 0.25, 0.15])
+    mat["kind"] = kinds
+    mat["albedo"] = rng.uniform(0.1, 1.0, (n, 3))
+    mat["fuzz"] = np.where(kinds == 1, rng.uniform(0, 0.6, n) * (rng.random(n) < 0.7), 0)
+    mat["ior"] = np.where(kinds == 2, rng.uniform(1.2, 2.0, n), 0)
+    hollow = (kinds == 2) & (rng.random(n) < 0.3)
+    sph["radius"] = np.where(hollow, -sph["radius"], sph["radius"])
+    if rng.random() < 0.7:      # a ground sphere far larger than everything else
+        sph[0] = (0.0, -1000.0 * scale - 0.3 * scale, 0.0, 1000.0 * scale)
+        mat[0] = (0, (0.5, 0.5, 0.5), 0.0, 0.0, (0, 0))
+    return sph, mat
+
+
+@pytest.mark.parametrize("case", range(20))
+def test_random_scene_all_kernels(gpu_ctx, oracle, case):
+    rng = np.random.default_rng(1000 + case)
+    n = int(rng.choice([1, 2, 7, 33, 100, 257, 700, 1500]))
+    scale = float(rng.choice([0.01, 1.0, 1.0, 50.0, 3000.0]))
+    sph, mat = _random_scene(rng, n, scale)
+    w, h = int(rng.integers(9, 90)), int(rng.integers(5, 60))
+    dist = float(rng.choice([0.5, 2.0, 2.0, 6.0, 40.0, 1500.0])) * scale   # inside, near, far, absurdly far
+    frm = rng.normal(size=3)
+    frm = frm / np.linalg.norm(frm) * dist + np.array([0, 0.5 * scale * rng.random(), 0])
+    cam = V.make_camera(tuple(frm), (0.0, 0.0, 0.0), (0, 1, 0), float(rng.uniform(15, 80)), w / h,
+                        float(rng.choice([0.0, 0.02, 0.3])) * scale, max(dist, 1e-3))
+    spp = int(rng.integers(1, 7))
+    depth = int(rng.choice([1, 3, 12, 50]))
+    base = dict(spp=spp, max_depth=depth, seed=int(rng.integers(0, 2**31)), quantiser=int(rng.integers(0, 2)))
+    want, segs = oracle.render(sph, mat, cam, V.make_params(w, h, **base))
+    gpu_ctx.set_scene(sph, mat)
+    for kernel in (V.KERNEL_PIXEL, V.KERNEL_PERSISTENT, V.KERNEL_CLUSTERED):
+        got = gpu_ctx.render(cam, V.make_params(w, h, kernel=kernel, **base))
+        st = gpu_ctx.stats()
+        bad = int((got != want).any(axis=2).sum())
+        assert bad == 0, (case, kernel, n, scale, dist, bad)
+        assert st.segments == segs, (case, kernel)

@@ -25,6 +25,8 @@ struct RtContext {
     uint32_t* d_cidx = nullptr;
     float4* d_cbounds = nullptr;
     uint32_t n_clusters = 0;
+    float cluster_center[3] = {0, 0, 0};
+    float cluster_diag = 0;
     uint32_t n_spheres = 0;
     rtiow::Counters* d_counters = nullptr;
     rtiow::Counters* h_counters = nullptr;  // pinned
@@ -204,6 +206,8 @@ int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materi
     RT_HIP(ctx, hipMemcpy(ctx->d_cidx, cs.idx.data(), sizeof(uint32_t) * cs.idx.size(), hipMemcpyHostToDevice));
     RT_HIP(ctx, hipMemcpy(ctx->d_cbounds, cs.bounds.data(), sizeof(float4) * cs.bounds.size(), hipMemcpyHostToDevice));
     ctx->n_clusters = cs.n_clusters;
+    for (int k = 0; k < 3; ++k) ctx->cluster_center[k] = cs.center[k];
+    ctx->cluster_diag = cs.diag;
     ctx->n_spheres = n_spheres;
     return RT_OK;
 }
@@ -294,7 +298,19 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         a.dst = out;
         a.dst_stride = out_stride;
         a.counters = ctx->d_counters;
-        RT_HIP(ctx, rtiow::launch_path(a, prm->kernel, prm->chunk_spp, ctx->num_cus, stream));
+        // The cluster bounds are inflated for ray origins within 4 scene diagonals of the scene's centre
+        // (rtiow_clusters.cpp).  A camera farther out gets the flat list: same frame, no assumption.
+        uint32_t kernel = prm->kernel;
+        if (kernel == rtiow::KERNEL_CLUSTERED || kernel == rtiow::KERNEL_DEFAULT) {
+            double d2 = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                const double d = double(cam->origin[k]) - double(ctx->cluster_center[k]);
+                d2 += d * d;
+            }
+            const double reach = 3.5 * double(ctx->cluster_diag) + double(cam->lens_radius);
+            if (!(d2 <= reach * reach)) kernel = rtiow::KERNEL_PERSISTENT;
+        }
+        RT_HIP(ctx, rtiow::launch_path(a, kernel, prm->chunk_spp, ctx->num_cus, stream));
     }
     RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream));
     RT_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(rtiow::Counters),

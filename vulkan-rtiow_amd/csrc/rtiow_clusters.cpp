@@ -67,6 +67,8 @@ void build_clusters(const RtSphere* sph, uint32_t n, ClusterScene& out) {
     // Rays start inside a few scene diameters of the spheres; |oc|^2 up to (4 diag)^2 = 16 diag2.
     // binary32 error of hb^2 - (|oc|^2 - R^2) is a few ulps of |oc|^2: keep 64 ulps of margin in R^2.
     const double r2_margin = 16.0 * diag2 * 64.0 * 5.96e-8 + 1e-6;
+    for (int k = 0; k < 3; ++k) out.center[k] = static_cast<float>(0.5 * (alo[k] + ahi[k]));
+    out.diag = static_cast<float>(std::sqrt(diag2));
 
     std::vector<uint32_t> code(n, 0u);
     for (uint32_t i : small) {

@@ -71,6 +71,9 @@ struct ClusterScene {  // host-side result of build_clusters
     std::vector<uint32_t> idx;
     std::vector<ClusterF4> bounds;
     uint32_t n_clusters = 0;
+    float center[3] = {0, 0, 0};  // of the clustered spheres
+    float diag = 0;               // their extent: ray origins farther than 4 diag from the centre are
+                                  // outside the rounding margin the bounds were inflated for
 };
 void build_clusters(const RtSphere* spheres, uint32_t n, ClusterScene& out);
 
