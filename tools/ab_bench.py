@@ -10,6 +10,7 @@ args = [a for a in sys.argv[1:] if a.endswith(".so")]
 spp = int(sys.argv[sys.argv.index("--spp") + 1]) if "--spp" in sys.argv else 100
 rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 5
 grid = int(sys.argv[sys.argv.index("--grid") + 1]) if "--grid" in sys.argv else 11
+tileG = int(sys.argv[sys.argv.index("--tile") + 1]) if "--tile" in sys.argv else 1
 kernels = [int(k) for k in sys.argv[sys.argv.index("--kernels") + 1].split(",")] if "--kernels" in sys.argv else [0]
 w, h = (1200, 800)
 sph, mat = V.make_cover_scene(1, grid)
@@ -25,14 +26,14 @@ for path in args:
     assert lib.rtSetScene(h_, sph.ctypes.data, mat.ctypes.data, len(sph)) == 0
     libs.append((path, lib, h_))
 import numpy as np
-out = np.zeros((h, w, 4), np.uint8)
+out = np.zeros((V.tile_row_count(h, 4, 0, tileG), w, 4), np.uint8)
 libs = [(f"{p}:k{k}", lib, h_, k) for p, lib, h_ in libs for k in kernels]
 times = {p: [] for p, _, _, _ in libs}
 tests = {}
 crc = {}
 for r in range(rounds + 1):
     for path, lib, h_, k in libs:
-        prm = V.make_params(w, h, spp=spp, max_depth=50, seed=1, kernel=k)
+        prm = V.make_params(w, h, spp=spp, max_depth=50, seed=1, kernel=k, row_block=4, tile_rank=0, tile_count=tileG)
         assert lib.rtRender(h_, C.byref(cam), C.byref(prm), out.ctypes.data, w * 4, 0, None) == 0
         st = V.RtStats()
         lib.rtGetStats(h_, C.byref(st))

@@ -444,9 +444,15 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 // sphere's first root in (t_min, inf), ties to the lowest index — exactly what
 // the oracle's sequential scan computes.
 
+#ifndef RTIOW_POOL_SAMPLES
+#define RTIOW_POOL_SAMPLES 384u  // measured (tools/ab_bench.py): 100 -> 36.3 ms, 200 -> 31.3, 300..512 -> 29.8, 2048 -> 32.6
+#endif
 constexpr int kSlots = 2;           // path slots per lane
 constexpr uint32_t kBlockSph = 32;  // spheres per candidate word
-constexpr uint32_t kSparseMax = 16; // live paths per wave at or below which the sphere-parallel trace runs
+#ifndef RTIOW_SPARSE_MAX
+#define RTIOW_SPARSE_MAX 16
+#endif
+constexpr uint32_t kSparseMax = RTIOW_SPARSE_MAX; // live paths per wave at or below which the sphere-parallel trace runs
 constexpr uint32_t kTailPool = 112; // paths a workgroup's tail pool holds (the adopter keeps <= 16 of its own)
 constexpr uint32_t kTailRecWords = 16;  // 64-byte parked-path records
 constexpr uint32_t kTailBytes = 16u + kTailPool * kTailRecWords * 4u;  // counters + records
@@ -1090,7 +1096,7 @@ hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, in
     g.n_pad = accel ? a.n_clusters * kClusterStride : (a.n + kBlockSph - 1u) / kBlockSph * kBlockSph;
     (void)max_take;  // scheduling is per sample now; the hint is accepted and ignored
     g.total_pix = a.local_rows * a.width;
-    g.pool_pix = 2048u / a.spp;  // ~2048 samples per pool away from the tail
+    g.pool_pix = RTIOW_POOL_SAMPLES / a.spp;  // a few pixels per pool; one pixel when spp is large
     g.pool_pix = g.pool_pix < 1u ? 1u : (g.pool_pix > 256u ? 256u : g.pool_pix);
     // LDS per workgroup: the sphere list (16 B per slot; clustered: + 4 B per slot of indices and
     // 16 B per cluster bound); while the scene is small, the shading records too (32 B each);
