@@ -111,6 +111,8 @@ def main():
                          "GPU (clean per-kernel roofline), 2 on several (a frame's tail of long paths and its "
                          "gather overlap the next frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extras (two frames in flight, the other kernel): profiling runs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -248,7 +250,7 @@ def main():
                               "bytes_per_launch": fb_bytes},
             },
         }
-        quick = ms_per_step < 500.0  # the extras below re-render the frame a few times
+        quick = ms_per_step < 500.0 and not args.no_extras  # the extras below re-render the frame a few times
         if world == 1 and F == 1 and quick:  # throughput of the same loop with two frames in flight (not `value`)
             c2 = V.Context(local_rank)
             c2.set_scene(sph, mat)

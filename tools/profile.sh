@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline $EXTRA"
+BENCH="python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_stats -- $BENCH > $O/prof_${TAG}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_${TAG}_fetch -- $BENCH > $O/prof_${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_${TAG}_write -- $BENCH > $O/prof_${TAG}_write.log 2>&1

@@ -13,8 +13,7 @@ namespace rtiow {
 struct Counters {
     unsigned long long paths;
     unsigned long long segments;
-    unsigned int queue_head_pix;    // persistent kernel: next pixel of the global pool queue
-    unsigned int pad32;
+    unsigned int xcd_head[8];       // persistent kernel: heads of the eight per-XCD pixel queues
     unsigned long long tests;       // ray-sphere and ray-bound tests performed
     unsigned long long debug[8];    // diagnostic builds (-DRTIOW_DEBUG_COUNTERS) only
 };

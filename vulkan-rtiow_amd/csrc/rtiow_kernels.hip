@@ -456,6 +456,7 @@ constexpr uint32_t kSparseMax = RTIOW_SPARSE_MAX; // live paths per wave at or b
 constexpr uint32_t kTailPool = 112; // paths a workgroup's tail pool holds (the adopter keeps <= 16 of its own)
 constexpr uint32_t kTailRecWords = 16;  // 64-byte parked-path records
 constexpr uint32_t kTailBytes = 16u + kTailPool * kTailRecWords * 4u;  // counters + records
+constexpr uint32_t kChunkPix = 256;                  // pixels per XCD-queue chunk (eight 128-byte lines of the frame)
 constexpr uint32_t kAccEntries = 64;                 // pixels a wave may have in flight
 constexpr uint32_t kAccWords = 4;                    // u64 words per entry: r, g, b, samples done
 constexpr uint32_t kWaveAccBytes = kAccEntries * kAccWords * 8u;  // 2 KiB of LDS per wave
@@ -516,7 +517,7 @@ DI void trace_slots(const float4* lds, uint32_t n_pad, uint32_t n, Slot (&sl)[R]
         uint32_t miss[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) miss[r] = 0u;
-#pragma unroll 8
+#pragma unroll 4
         for (uint32_t j = 0; j < kBlockSph; ++j) {
             const float4 s = lds[base + j];  // wave-uniform address: LDS broadcast
 #pragma unroll
@@ -761,7 +762,10 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
         sl[r].p.o = sl[r].p.du = sl[r].p.att = mk(0.0f, 0.0f, 0.0f);
     }
     // wave-uniform queue state (SGPRs)
-    uint32_t pool_next = 0u, pool_end = 0u;  // pixels of the wave's pool not yet begun
+    uint32_t pool_next = 0u, pool_end = 0u;  // the wave's pool: virtual pixel indices of queue pool_xcd not yet begun
+    uint32_t pool_xcd = 0u, steal = 0u;      // the queue it came from; queues found dry so far
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;  // HW_REG_XCC_ID[3:0]
+    const uint32_t n_chunks = (g.total_pix + kChunkPix - 1u) / kChunkPix;
     uint32_t cur_pix = 0u, cur_entry = 0u;   // pixel being handed out and its accumulator entry
     uint32_t cur_s = a.spp;                  // its next sample; == spp: no pixel open
     unsigned long long free_entries = ~0ull; // accumulator entries not in use
@@ -794,29 +798,55 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
             while (served < want) {  // one trip per pixel touched (1-2 unless spp is tiny)
                 if (cur_s == a.spp) {  // open the next pixel of the pool
                     if (pool_next == pool_end) {
-                        if (exhausted) break;
-                        // pool fetch: one atomic per wave per pool.  Guided size from the CURRENT
-                        // head (a stale one would let a wave grab a full pool of the last pixels).
-                        uint32_t head_now = 0u;
-                        if (lane == 0u)
-                            head_now = __hip_atomic_load(&a.counters->queue_head_pix, __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT);
-                        head_now = __builtin_amdgcn_readfirstlane(head_now);
-                        const uint32_t rem_pix = g.total_pix - (head_now < g.total_pix ? head_now : g.total_pix);
-                        uint32_t k = rem_pix / (g.total_waves * 2u);
-                        k = k < 1u ? 1u : (k > g.pool_pix ? g.pool_pix : k);
-                        uint32_t got = 0u;
-                        if (lane == 0u) got = atomicAdd(&a.counters->queue_head_pix, k);
-                        got = __builtin_amdgcn_readfirstlane(got);
-                        if (got + k >= g.total_pix || got + k < got) exhausted = true;
-                        if (got >= g.total_pix) break;
-                        pool_next = got;
-                        pool_end = g.total_pix - got < k ? g.total_pix : got + k;
+                        // Pool fetch: one atomic per wave per pool.  The tile's pixels are cut into chunks
+                        // of kChunkPix consecutive pixels dealt round-robin to eight queues, one per XCD:
+                        // a wave draws from the queue of the XCD it runs on, so the 4-byte stores that
+                        // complete a 128-byte line of the frame all come from one L2 and merge there.
+                        // An XCD whose queue is dry steals from the next one.  Pool size is guided from
+                        // the CURRENT head (a stale one would let a wave grab a full pool at the very end).
+                        bool fetched = false;
+                        while (steal < 8u && !fetched) {
+                            const uint32_t xq = (xcc + steal) & 7u;
+                            const uint32_t vsize = ((n_chunks + 7u - xq) / 8u) * kChunkPix;  // virtual pixels of queue xq
+                            uint32_t head_now = 0u;
+                            if (lane == 0u)
+                                head_now = __hip_atomic_load(&a.counters->xcd_head[xq], __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT);
+                            head_now = __builtin_amdgcn_readfirstlane(head_now);
+                            if (head_now < vsize) {
+                                uint32_t k = (vsize - head_now) / (g.total_waves / 4u + 1u);  // ~waves per XCD x 2
+                                k = k < 1u ? 1u : (k > g.pool_pix ? g.pool_pix : k);
+                                uint32_t got = 0u;
+                                if (lane == 0u) got = atomicAdd(&a.counters->xcd_head[xq], k);
+                                got = __builtin_amdgcn_readfirstlane(got);
+                                if (got < vsize) {
+                                    pool_next = got;
+                                    pool_end = vsize - got < k ? vsize : got + k;
+                                    pool_xcd = xq;
+                                    fetched = true;
+                                    break;
+                                }
+                            }
+                            ++steal;  // this queue is dry for good: heads only grow
+                        }
+                        if (!fetched) {
+                            exhausted = true;
+                            break;
+                        }
+                    }
+                    {   // virtual index of queue pool_xcd -> pixel of the tile
+                        const uint32_t v = pool_next;
+                        const uint32_t pix = ((v / kChunkPix) * 8u + pool_xcd) * kChunkPix + v % kChunkPix;
+                        if (pix >= g.total_pix) {  // the ragged end of the last chunk
+                            ++pool_next;
+                            continue;
+                        }
                     }
                     if (free_entries == 0ull) break;  // 64 pixels in flight: wait for one to finish
                     cur_entry = static_cast<uint32_t>(__builtin_ctzll(free_entries));
                     free_entries &= free_entries - 1ull;
-                    cur_pix = pool_next++;
+                    cur_pix = ((pool_next / kChunkPix) * 8u + pool_xcd) * kChunkPix + pool_next % kChunkPix;
+                    ++pool_next;
                     cur_s = 0u;
                     if (lane < kAccWords) lds_acc[(wave_in_group * kAccEntries + cur_entry) * kAccWords + lane] = 0ull;
                 }
@@ -841,7 +871,7 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
             any_active = any_active || q.active;
         }
         // ---- tail merge: pool the workgroup's leftovers in one wave ----------------------
-        if (!tail_done && donate_max != 0u && exhausted && pool_next == pool_end && cur_s == a.spp) {
+        if (!tail_done && donate_max != 0u && exhausted && cur_s == a.spp) {
             uint32_t live = 0u;
 #pragma unroll
             for (int r = 0; r < kSlots; ++r) live += static_cast<uint32_t>(__popcll(__ballot(sl[r].active)));
