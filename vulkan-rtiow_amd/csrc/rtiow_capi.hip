@@ -24,9 +24,9 @@ struct RtContext {
     float4* d_cslots = nullptr;   // clustered list (rtiow_clusters.cpp)
     uint32_t* d_cidx = nullptr;
     float4* d_cbounds = nullptr;
-    uint32_t n_clusters = 0;
+    uint32_t n_clusters = 0, n_large = 0, n_large_slots = 0, n_cslots = 0;
     float cluster_center[3] = {0, 0, 0};
-    float cluster_diag = 0;
+    float cluster_diag = 0, cluster_rmax2 = 0;
     uint32_t n_spheres = 0;
     rtiow::Counters* d_counters = nullptr;
     rtiow::Counters* h_counters = nullptr;  // pinned
@@ -206,8 +206,12 @@ int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materi
     RT_HIP(ctx, hipMemcpy(ctx->d_cidx, cs.idx.data(), sizeof(uint32_t) * cs.idx.size(), hipMemcpyHostToDevice));
     RT_HIP(ctx, hipMemcpy(ctx->d_cbounds, cs.bounds.data(), sizeof(float4) * cs.bounds.size(), hipMemcpyHostToDevice));
     ctx->n_clusters = cs.n_clusters;
+    ctx->n_large = cs.n_large;
+    ctx->n_large_slots = cs.n_large_slots;
+    ctx->n_cslots = static_cast<uint32_t>(cs.slots.size());
     for (int k = 0; k < 3; ++k) ctx->cluster_center[k] = cs.center[k];
     ctx->cluster_diag = cs.diag;
+    ctx->cluster_rmax2 = cs.rmax2;
     ctx->n_spheres = n_spheres;
     return RT_OK;
 }
@@ -266,6 +270,11 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         a.cidx = ctx->d_cidx;
         a.cbounds = ctx->d_cbounds;
         a.n_clusters = ctx->n_clusters;
+        a.n_large = ctx->n_large;
+        a.n_large_slots = ctx->n_large_slots;
+        a.n_cslots = ctx->n_cslots;
+        for (int k = 0; k < 3; ++k) a.ccenter[k] = ctx->cluster_center[k];
+        a.crmax2 = ctx->cluster_rmax2;
         a.n = ctx->n_spheres;
         a.cam = *cam;
         a.width = W;
@@ -298,8 +307,9 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         a.dst = out;
         a.dst_stride = out_stride;
         a.counters = ctx->d_counters;
-        // The cluster bounds are inflated for ray origins within 4 scene diagonals of the scene's centre
-        // (rtiow_clusters.cpp).  A camera farther out gets the flat list: same frame, no assumption.
+        // The cluster boxes are inflated for ray origins within 2 scene diagonals of the scene's centre
+        // (rtiow_clusters.cpp); the kernel sends any ray that starts farther out through every cluster.
+        // A camera out there would do that for all its primary rays: it gets the flat list instead.
         uint32_t kernel = prm->kernel;
         if (kernel == rtiow::KERNEL_CLUSTERED || kernel == rtiow::KERNEL_DEFAULT) {
             double d2 = 0.0;
@@ -307,8 +317,8 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
                 const double d = double(cam->origin[k]) - double(ctx->cluster_center[k]);
                 d2 += d * d;
             }
-            const double reach = 3.5 * double(ctx->cluster_diag) + double(cam->lens_radius);
-            if (!(d2 <= reach * reach)) kernel = rtiow::KERNEL_PERSISTENT;
+            const double reach = 1.9 * double(ctx->cluster_diag) - double(cam->lens_radius);
+            if (!(reach > 0.0 && d2 <= reach * reach)) kernel = rtiow::KERNEL_PERSISTENT;
         }
         RT_HIP(ctx, rtiow::launch_path(a, kernel, prm->chunk_spp, ctx->num_cus, stream));
     }

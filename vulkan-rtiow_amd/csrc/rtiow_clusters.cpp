@@ -1,14 +1,22 @@
 // rtiow_clusters.cpp — host-side build of the two-level sphere list used by the clustered
 // persistent kernel ("acceleration structure", not in the reference or
-// in RTIOW book 1; book 2's bvh_node is the natural next step after hittable_list).
+// in RTIOW book 1; book 2's bvh_node / aabb is the natural next step after hittable_list).
 //
-// Spheres are sorted along a Morton curve and cut into clusters of kClusterSize; each cluster gets
-// a bounding sphere.  Very large spheres (the ground) become clusters of their own whose bound IS
-// the sphere, bit for bit.  The kernel tests every cluster bound for every ray segment (wave in
-// lock-step, LDS broadcast) and then, lane by lane, only the members of the clusters the ray can
-// reach.  The result is the same closest hit the flat list gives — the bound of a cluster is
-// inflated far beyond the rounding error of the bound test, so no hit can be culled, and the
-// minimum over (distance, original index) does not depend on the order of the tests.
+// Very large spheres (the ground) go into a short list of their own that every ray tests exactly.
+// The others are grouped by recursive median splits into clusters of kClusterSize; each cluster gets
+// an axis-aligned box, stored as centre + half extent.  The kernel tests every box for every ray
+// segment (wave in lock-step, LDS broadcast, slab test) and then, lane by lane, only the members of
+// the boxes the ray can reach.
+//
+// The result is the same closest hit the flat list gives:
+//   * a member is found by the same discriminant / first-root-beyond-t_min arithmetic as in the flat
+//     list, and the minimum over (distance, original index) does not depend on the order of the tests;
+//   * a box can only cull spheres the exact test would reject.  binary32 evaluates the discriminant
+//     hb^2 - (|oc|^2 - r^2) with an absolute error below ~22 eps |oc|^2 (eps = 2^-24),
+//     so a ray the exact test accepts passes within sqrt(r^2 + E) of the centre, E = 48 eps |oc|max^2.
+//     Every member is boxed with that radius plus the slab test's own rounding (a shift of the planes
+//     by a few eps of the coordinates), for ray origins within rmax = 2 diag of the scene's centre;
+//     the kernel sends a ray that starts farther out through all clusters.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -20,13 +28,10 @@
 namespace rtiow {
 
 namespace {
-uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
-    v &= 0x3FFu;
-    v = (v | (v << 16)) & 0x030000FFu;
-    v = (v | (v << 8)) & 0x0300F00Fu;
-    v = (v | (v << 4)) & 0x030C30C3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
+float round_up(double v) {  // smallest float >= v
+    float f = static_cast<float>(v);
+    if (static_cast<double>(f) < v) f = std::nextafter(f, INFINITY);
+    return f;
 }
 }  // namespace
 
@@ -42,86 +47,113 @@ void build_clusters(const RtSphere* sph, uint32_t n, ClusterScene& out) {
     const float median = sorted_r[n / 2];
     std::vector<uint32_t> small, large;
     for (uint32_t i = 0; i < n; ++i) (radii[i] > 4.0f * median ? large : small).push_back(i);
-    // extent of the small spheres (for Morton codes) and of everything (for the rounding margin)
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    // extent of the small spheres' surfaces (for the margins)
     double alo[3] = {1e300, 1e300, 1e300}, ahi[3] = {-1e300, -1e300, -1e300};
-    for (uint32_t i = 0; i < n; ++i) {
-        const double c[3] = {sph[i].cx, sph[i].cy, sph[i].cz};
-        const bool is_small = radii[i] <= 4.0f * median;
-        for (int k = 0; k < 3; ++k) {
-            if (is_small) {
-                lo[k] = std::min(lo[k], c[k]);
-                hi[k] = std::max(hi[k], c[k]);
-            }
-            // the huge spheres count with the part of them near the others only: use the centres of
-            // the small ones and the surfaces of everything up to 16 median radii away
-            alo[k] = std::min(alo[k], is_small ? c[k] - radii[i] : alo[k]);
-            ahi[k] = std::max(ahi[k], is_small ? c[k] + radii[i] : ahi[k]);
-        }
-    }
-    if (small.empty()) {
-        for (int k = 0; k < 3; ++k) lo[k] = hi[k] = alo[k] = ahi[k] = 0.0;
-    }
-    double diag2 = 0.0;
-    for (int k = 0; k < 3; ++k) diag2 += (ahi[k] - alo[k]) * (ahi[k] - alo[k]);
-    // Rays start inside a few scene diameters of the spheres; |oc|^2 up to (4 diag)^2 = 16 diag2.
-    // binary32 error of hb^2 - (|oc|^2 - R^2) is a few ulps of |oc|^2: keep 64 ulps of margin in R^2.
-    const double r2_margin = 16.0 * diag2 * 64.0 * 5.96e-8 + 1e-6;
-    for (int k = 0; k < 3; ++k) out.center[k] = static_cast<float>(0.5 * (alo[k] + ahi[k]));
-    out.diag = static_cast<float>(std::sqrt(diag2));
-
-    std::vector<uint32_t> code(n, 0u);
     for (uint32_t i : small) {
-        uint32_t q[3];
         const double c[3] = {sph[i].cx, sph[i].cy, sph[i].cz};
         for (int k = 0; k < 3; ++k) {
-            const double span = hi[k] - lo[k];
-            q[k] = span > 0.0 ? static_cast<uint32_t>(std::min(1023.0, (c[k] - lo[k]) / span * 1023.0)) : 0u;
+            alo[k] = std::min(alo[k], c[k] - radii[i]);
+            ahi[k] = std::max(ahi[k], c[k] + radii[i]);
         }
-        code[i] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
     }
-    std::stable_sort(small.begin(), small.end(), [&](uint32_t a, uint32_t b) { return code[a] < code[b]; });
+    double diag2 = 0.0, cmax = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        diag2 += (ahi[k] - alo[k]) * (ahi[k] - alo[k]);
+        out.center[k] = static_cast<float>(0.5 * (alo[k] + ahi[k]));
+        cmax = std::max(cmax, std::fabs(static_cast<double>(out.center[k])));
+    }
+    const double diag = std::sqrt(diag2);
+    out.diag = static_cast<float>(diag);
+    // rays that start within rmax of the centre use the boxes; |oc| <= rmax + diag/2 for them
+    const double rmax = 2.0 * diag;
+    out.rmax2 = static_cast<float>(rmax * rmax);
+    constexpr double kEps = 5.9604644775390625e-8;  // 2^-24
+    const double oc_max = 2.5 * diag;               // rmax + diag/2, and the rounding of the kernel's own range check
+    const double r2_margin = 48.0 * kEps * oc_max * oc_max;
+    const double plane_margin = 64.0 * kEps * (cmax + 3.0 * diag) + 1e-30;
 
-    auto emit = [&](const uint32_t* members, uint32_t count, bool exact) {
-        // slots: kClusterStride per cluster, the first kClusterSize real or never-hit padding
-        const size_t base = out.slots.size();
-        out.slots.resize(base + kClusterStride, ClusterF4{0.0f, 0.0f, 0.0f, -1.0f});
-        out.idx.resize(base + kClusterStride, 0xFFFFFFFFu);
-        double c[3] = {0, 0, 0};
-        for (uint32_t m = 0; m < count; ++m) {
-            const RtSphere& s = sph[members[m]];
-            out.slots[base + m] = ClusterF4{s.cx, s.cy, s.cz, s.radius * s.radius};
-            out.idx[base + m] = members[m];
-            c[0] += s.cx; c[1] += s.cy; c[2] += s.cz;
-        }
-        ClusterF4 b;
-        if (exact) {  // a single large sphere: the bound test IS the sphere test, same floats
-            const RtSphere& s = sph[members[0]];
-            b = ClusterF4{s.cx, s.cy, s.cz, s.radius * s.radius};
-        } else {
-            for (double& v : c) v /= count;
-            const float cf[3] = {static_cast<float>(c[0]), static_cast<float>(c[1]), static_cast<float>(c[2])};
-            double r = 0.0;
-            for (uint32_t m = 0; m < count; ++m) {
-                const RtSphere& s = sph[members[m]];
-                const double dx = s.cx - double(cf[0]), dy = s.cy - double(cf[1]), dz = s.cz - double(cf[2]);
-                r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs(double(s.radius)));
+    // Order the small spheres so that every run of kClusterSize is a compact group: split the set at
+    // the median of its longest axis, the left part rounded to whole clusters, and recurse.  (Runs of a
+    // Morton curve give boxes a ray meets 2.1x as often on the cover scene: tools/cull_sim.py.)
+    struct Range { size_t lo, hi; };
+    std::vector<Range> todo{{0, small.size()}};
+    while (!todo.empty()) {
+        const Range rg = todo.back();
+        todo.pop_back();
+        const size_t count = rg.hi - rg.lo;
+        if (count <= kClusterSize) continue;
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t k = rg.lo; k < rg.hi; ++k) {
+            const float c[3] = {sph[small[k]].cx, sph[small[k]].cy, sph[small[k]].cz};
+            for (int d = 0; d < 3; ++d) {
+                mn[d] = std::min(mn[d], c[d]);
+                mx[d] = std::max(mx[d], c[d]);
             }
-            const double r2 = r * r * (1.0 + 1e-5) + r2_margin;
-            b = ClusterF4{cf[0], cf[1], cf[2], std::nextafter(static_cast<float>(r2), INFINITY)};
         }
-        out.bounds.push_back(b);
-    };
-    for (uint32_t i : large) emit(&i, 1u, true);
-    for (size_t k = 0; k < small.size(); k += kClusterSize)
-        emit(&small[k], static_cast<uint32_t>(std::min<size_t>(kClusterSize, small.size() - k)), false);
-    // pad the cluster count to a multiple of 8 (the unroll of the bound loop) with unreachable bounds
-    while (out.bounds.size() % 8u) {
-        out.bounds.push_back(ClusterF4{0.0f, 0.0f, 0.0f, -1.0f});
-        out.slots.resize(out.slots.size() + kClusterStride, ClusterF4{0.0f, 0.0f, 0.0f, -1.0f});
+        int axis = 0;
+        for (int d = 1; d < 3; ++d)
+            if (mx[d] - mn[d] > mx[axis] - mn[axis]) axis = d;
+        auto coord = [&](uint32_t i) { return axis == 0 ? sph[i].cx : (axis == 1 ? sph[i].cy : sph[i].cz); };
+        std::stable_sort(small.begin() + rg.lo, small.begin() + rg.hi, [&](uint32_t x, uint32_t y) {
+            const float cx = coord(x), cy = coord(y);
+            return cx < cy || (cx == cy && x < y);
+        });
+        size_t left = (count / 2 + kClusterSize / 2) / kClusterSize * kClusterSize;
+        if (left == 0) left = kClusterSize;
+        if (left >= count) left = count - 1;
+        todo.push_back({rg.lo, rg.lo + left});
+        todo.push_back({rg.lo + left, rg.hi});
+    }
+
+    const ClusterF4 never{0.0f, 0.0f, 0.0f, -1.0f};  // r^2 = -1: the discriminant is negative for every ray
+    // the large spheres: one group of slots, padded to whole clusters (the sparse trace scans all slots)
+    out.n_large_slots = static_cast<uint32_t>((large.size() + kClusterSize - 1u) / kClusterSize * kClusterSize);
+    out.slots.assign(out.n_large_slots, never);
+    out.idx.assign(out.n_large_slots, 0xFFFFFFFFu);
+    for (size_t m = 0; m < large.size(); ++m) {
+        const RtSphere& s = sph[large[m]];
+        out.slots[m] = ClusterF4{s.cx, s.cy, s.cz, s.radius * s.radius};
+        out.idx[m] = large[m];
+    }
+    out.n_large = static_cast<uint32_t>(large.size());
+
+    for (size_t k0 = 0; k0 < small.size(); k0 += kClusterSize) {
+        const uint32_t count = static_cast<uint32_t>(std::min<size_t>(kClusterSize, small.size() - k0));
+        const size_t base = out.slots.size();
+        out.slots.resize(base + kClusterStride, never);
+        out.idx.resize(base + kClusterStride, 0xFFFFFFFFu);
+        double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+        for (uint32_t m = 0; m < count; ++m) {
+            const RtSphere& s = sph[small[k0 + m]];
+            out.slots[base + m] = ClusterF4{s.cx, s.cy, s.cz, s.radius * s.radius};
+            out.idx[base + m] = small[k0 + m];
+            const double c[3] = {s.cx, s.cy, s.cz};
+            const double ext = std::sqrt(double(s.radius) * double(s.radius) + r2_margin) + plane_margin;
+            for (int k = 0; k < 3; ++k) {
+                blo[k] = std::min(blo[k], c[k] - ext);
+                bhi[k] = std::max(bhi[k], c[k] + ext);
+            }
+        }
+        ClusterF4 mid{0, 0, 0, 0}, half{0, 0, 0, 0};
+        float* mp[3] = {&mid.x, &mid.y, &mid.z};
+        float* hp[3] = {&half.x, &half.y, &half.z};
+        for (int k = 0; k < 3; ++k) {
+            const float m = static_cast<float>(0.5 * (blo[k] + bhi[k]));
+            *mp[k] = m;
+            *hp[k] = round_up(std::max(bhi[k] - double(m), double(m) - blo[k]));
+        }
+        out.bounds.push_back(mid);
+        out.bounds.push_back(half);
+    }
+    // pad the cluster count to a multiple of 4 (the unroll of the box loop) with empty clusters whose
+    // box is a point far outside any scene (reaching it by accident only costs 16 never-hit tests)
+    while ((out.bounds.size() / 2u) % 4u) {
+        out.bounds.push_back(ClusterF4{3e18f, 3e18f, 3e18f, 0.0f});
+        out.bounds.push_back(ClusterF4{0.0f, 0.0f, 0.0f, 0.0f});
+        out.slots.resize(out.slots.size() + kClusterStride, never);
         out.idx.resize(out.idx.size() + kClusterStride, 0xFFFFFFFFu);
     }
-    out.n_clusters = static_cast<uint32_t>(out.bounds.size());
+    out.n_clusters = static_cast<uint32_t>(out.bounds.size() / 2u);
 }
 
 }  // namespace rtiow

@@ -27,19 +27,26 @@ struct ShadeRec {
     uint32_t pad[2];
 };
 
-// Two-level sphere list of the clustered kernel (rtiow_clusters.cpp): clusters of kClusterSize
-// members, kClusterStride slots apart.  With the lane-rotated member order of the kernel, a stride of
-// 16 slots (256 B = one LDS bank row) makes the bank of a read depend on the lane only: conflict-free.
+// Two-level sphere list of the clustered kernel (rtiow_clusters.cpp): the large spheres first, then
+// clusters of kClusterSize members, kClusterStride slots apart.  With the lane-rotated member order of
+// the kernel, a stride of 16 slots (256 B = one LDS bank row) makes the bank of a read depend on the
+// lane only: conflict-free.
 constexpr uint32_t kClusterSize = 16, kClusterStride = 16;
 
 struct PathArgs {
     const float4* spheres;       // n x {cx,cy,cz,radius} as uploaded (RtSphere)
     const ShadeRec* shade;       // n x 32 B
     uint32_t n;
-    const float4* cslots;        // clustered: n_clusters x kClusterStride x {cx,cy,cz,r*r}; padding never hit
+    const float4* cslots;        // clustered: n_cslots x {cx,cy,cz,r*r}; padding never hit.  The first
+                                 // n_large_slots hold the large spheres, then kClusterStride per cluster
     const uint32_t* cidx;        // clustered: original index of every slot (0xFFFFFFFF = padding)
-    const float4* cbounds;       // clustered: n_clusters x {Cx,Cy,Cz,R*R}
-    uint32_t n_clusters;         // multiple of 8
+    const float4* cbounds;       // clustered: n_clusters x {box centre, box half extent}
+    uint32_t n_clusters;         // multiple of 4
+    uint32_t n_large;            // large spheres (tested exactly by every ray)
+    uint32_t n_large_slots;      // their slots: n_large padded to a multiple of kClusterSize
+    uint32_t n_cslots;           // n_large_slots + n_clusters * kClusterStride
+    float ccenter[3];            // boxes are valid for ray origins with |o - ccenter|^2 <= crmax2
+    float crmax2;
     RtCamera cam;
     uint32_t width, height;      // full image
     uint32_t spp, max_depth, seed, quantiser;
@@ -68,11 +75,13 @@ struct ClusterF4 {
 struct ClusterScene {  // host-side result of build_clusters
     std::vector<ClusterF4> slots;
     std::vector<uint32_t> idx;
-    std::vector<ClusterF4> bounds;
+    std::vector<ClusterF4> bounds;  // two per cluster: centre, half extent
     uint32_t n_clusters = 0;
+    uint32_t n_large = 0, n_large_slots = 0;
     float center[3] = {0, 0, 0};  // of the clustered spheres
-    float diag = 0;               // their extent: ray origins farther than 4 diag from the centre are
-                                  // outside the rounding margin the bounds were inflated for
+    float diag = 0;               // their extent
+    float rmax2 = 0;              // (2 diag)^2: ray origins farther from the centre are outside the
+                                  // rounding margin the boxes were inflated for
 };
 void build_clusters(const RtSphere* spheres, uint32_t n, ClusterScene& out);
 
@@ -80,7 +89,7 @@ enum : uint32_t {
     KERNEL_DEFAULT = 0,
     KERNEL_PIXEL = 1,      // one lane per pixel, spp loop inside (v1)
     KERNEL_PERSISTENT = 2, // persistent waves, flat sphere list (every ray tests every sphere)
-    KERNEL_CLUSTERED = 3   // persistent waves, two-level list: cluster bounds, then members per lane
+    KERNEL_CLUSTERED = 3   // persistent waves, two-level list: cluster boxes, then members per lane
 };
 
 hipError_t launch_ch(const ChArgs& a, hipStream_t stream);

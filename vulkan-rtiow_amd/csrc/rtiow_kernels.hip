@@ -620,100 +620,220 @@ DI void trace_sparse(const float4* list, const uint32_t* idx_map, uint32_t n_slo
     }
 }
 
-// Two-level closest hit (SURVEY f-4).  Phase 1, wave in lock-step: every cluster bound against every
-// live ray (LDS broadcast), one candidate bit per cluster — bound reached in front of the origin, or
-// origin inside it.  Phase 2, lane by lane: the 16 members of each candidate cluster; lanes read
-// their own cluster, rotated by the lane number so that the 16 lanes of an LDS access group touch 16
-// different bank quads whatever clusters they are on.  Members go through the same discriminant /
-// candidate-word / first-root-beyond-t_min rule as the flat list, and the hit is the minimum of
+// Two-level closest hit (SURVEY f-4).  Phase 0, wave in lock-step: the few large spheres, exactly as
+// the flat list does it.  Phase 1, wave in lock-step: the box of every cluster against every live ray
+// (LDS broadcast; slab test on centre + half extent with the ray's reciprocal direction), one candidate
+// bit per cluster.  Phase 2, lane by lane: the 16 members of each candidate cluster; lanes read their own
+// cluster, rotated by the lane number so that the 16 lanes of an LDS access group touch 16 different
+// bank quads whatever clusters they are on.  Members go through the same discriminant / candidate-word /
+// first-root-beyond-t_min rule as the flat list, and the hit is the minimum of
 // (root bits << 32 | original index): the same sphere the flat scan returns, ties included.
-DI void examine_keyed(const float4* slots, const uint32_t* idx_map, uint32_t slot, const Path& p,
-                      unsigned long long& key, uint32_t& kslot) {
-    const uint32_t orig = idx_map[slot];
-    if (orig == 0xFFFFFFFFu) return;  // padding
+// The slab test only has to be conservative (rtiow_clusters.cpp sizes the boxes for its rounding and
+// the exact test's), so it may use v_rcp_f32 and any operation order; it never decides a hit.
+// key = root bits << 32 | original index << 16 | slot (both below 65536: rtSetScene caps the scene)
+DI void examine_keyed(const float4* slots, const uint32_t* idx_map, uint32_t slot, const float ox, const float oy,
+                      const float oz, const float dx, const float dy, const float dz, unsigned long long& key) {
     const float4 s = slots[slot];
-    const float ocx = p.o.x - s.x, ocy = p.o.y - s.y, ocz = p.o.z - s.z;
-    const float hb = fma_(ocz, p.du.z, fma_(ocy, p.du.y, ocx * p.du.x));
+    const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
+    const float hb = fma_(ocz, dz, fma_(ocy, dy, ocx * dx));
     const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
     const float disc = fma_(hb, hb, -cc);
-    if (__builtin_signbit(disc) || disc != disc) return;
+    if (__builtin_signbit(disc) || disc != disc) return;  // (padding slots, r^2 = -1, always leave here)
     const float sq = __builtin_sqrtf(disc);
     float root = -hb - sq;
     root = root > kTMin ? root : -hb + sq;
     if (!(root > kTMin)) return;
-    const unsigned long long k2 = (static_cast<unsigned long long>(__float_as_uint(root)) << 32) | orig;
-    if (k2 < key) {
-        key = k2;
-        kslot = slot;
+    const uint32_t orig = idx_map[slot];
+    const unsigned long long k2 =
+        (static_cast<unsigned long long>(__float_as_uint(root)) << 32) | (orig << 16) | slot;
+    key = k2 < key ? k2 : key;
+}
+
+// the 16 members of the cluster whose slots start at `base`, for one ray
+DI void examine_cluster(const float4* slots, const uint32_t* idx_map, uint32_t base, uint32_t lane, const float ox,
+                        const float oy, const float oz, const float dx, const float dy, const float dz,
+                        unsigned long long& key) {
+    uint32_t mm = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < kClusterSize; ++k) {
+        const float4 s = slots[base + ((k + lane) & (kClusterSize - 1u))];
+        const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
+        const float hb = fma_(ocz, dz, fma_(ocy, dy, ocx * dx));
+        const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
+        const float disc = fma_(hb, hb, -cc);
+        mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(disc), 31);
+    }
+    uint32_t cand = ~mm & 0xFFFFu;  // bit 15-k: member step k
+    while (cand) {
+        const uint32_t k = static_cast<uint32_t>(__builtin_clz(cand)) - 16u;
+        cand &= ~(0x8000u >> k);
+        examine_keyed(slots, idx_map, base + ((k + lane) & (kClusterSize - 1u)), ox, oy, oz, dx, dy, dz, key);
     }
 }
 
+DI float slab_rcp(float d) {  // reciprocal of a direction component kept away from zero (finite slabs, no NaN)
+    const float c = __builtin_fabsf(d) < 1e-18f ? __builtin_copysignf(1e-18f, d) : d;
+    return __builtin_amdgcn_rcpf(c);
+}
+
+// Per-wave LDS of the clustered trace: the work list of phase 2 and the per-ray results.
+constexpr uint32_t kItemCap = 512;                          // (ray, cluster) items per slot and group of 32 clusters
+constexpr uint32_t kWaveItemBytes = kItemCap * 2u + 128u * 8u;  // u16 items + one u64 key per path slot
+
+// Phase 2 is where rays diverge: a ray reaches 3 clusters on average, the unluckiest of a wave's 64
+// four times that, so a loop "each lane walks its own clusters" runs at 25 % utilisation.  Instead the
+// wave pools its (ray, cluster) pairs in an LDS list — a prefix sum over the lanes' candidate counts
+// gives every lane the place of its items — and works through the list 64 items at a time, one
+// cluster per lane: the lane fetches the ray of the item (ds_bpermute), tests the 16 members and folds
+// the hit into the ray's result with an LDS atomic minimum on the packed key.  The minimum is
+// order-independent, so the result is the one the per-lane walk gives.
 template <int R>
-DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const float4* bounds, uint32_t n_clusters,
+DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const float4* bounds, const PathArgs& a,
+                        uint16_t* items, unsigned long long* results,
                         Slot (&sl)[R], float (&best)[R], int (&best_i)[R], uint32_t (&best_o)[R],
-                        uint32_t& n_tests) {
+                        uint32_t& n_tests, uint32_t& dbg_slow_trips, uint32_t& dbg_cands,
+                        unsigned long long& dbg_t_slow) {
     const uint32_t lane = threadIdx.x & 63u;
     unsigned long long key[R];
-    uint32_t kslot[R];
+    float ix[R], iy[R], iz[R], ax[R], ay[R], az[R];
+    bool outside[R];  // ray origin beyond the range the boxes were inflated for: take every cluster
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         key[r] = ~0ull;
-        kslot[r] = 0u;
+        results[r * 64 + lane] = ~0ull;
+        const Path& p = sl[r].p;
+        ix[r] = slab_rcp(p.du.x);
+        iy[r] = slab_rcp(p.du.y);
+        iz[r] = slab_rcp(p.du.z);
+        ax[r] = -p.o.x * ix[r];
+        ay[r] = -p.o.y * iy[r];
+        az[r] = -p.o.z * iz[r];
+        const float qx = p.o.x - a.ccenter[0], qy = p.o.y - a.ccenter[1], qz = p.o.z - a.ccenter[2];
+        outside[r] = !(fma_(qz, qz, fma_(qy, qy, qx * qx)) <= a.crmax2);
     }
-    for (uint32_t g0 = 0; g0 < n_clusters; g0 += 32u) {
-        uint32_t cmask[R];
+    // ---- phase 0: the large spheres, every ray, exact ----
+    for (uint32_t base = 0; base < a.n_large; base += 32u) {
+        const uint32_t jn = a.n_large - base < 32u ? a.n_large - base : 32u;
+        uint32_t miss[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) cmask[r] = 0u;
-        const uint32_t jn = n_clusters - g0 < 32u ? n_clusters - g0 : 32u;  // n_clusters is a multiple of 8
-#pragma unroll 8
+        for (int r = 0; r < R; ++r) miss[r] = 0u;
         for (uint32_t j = 0; j < jn; ++j) {
-            const float4 b = bounds[g0 + j];  // wave-uniform address: LDS broadcast
+            const float4 s = slots[base + j];  // wave-uniform address: LDS broadcast
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const Path& p = sl[r].p;
-                const float ocx = p.o.x - b.x, ocy = p.o.y - b.y, ocz = p.o.z - b.z;
+                const float ocx = p.o.x - s.x, ocy = p.o.y - s.y, ocz = p.o.z - s.z;
                 const float hb = fma_(ocz, p.du.z, fma_(ocy, p.du.y, ocx * p.du.x));
-                const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -b.w)));
+                const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
                 const float disc = fma_(hb, hb, -cc);
-                const bool reach = !__builtin_signbit(disc) && disc == disc && (hb < 0.0f || cc < 0.0f);
-                cmask[r] = (cmask[r] << 1) | (reach ? 1u : 0u);
+                miss[r] = __builtin_amdgcn_alignbit(miss[r], __float_as_uint(disc), 31);
             }
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            uint32_t cm = sl[r].active ? cmask[r] << (32u - jn) : 0u;  // first cluster of the word at bit 31
+            uint32_t cand = sl[r].active ? ~miss[r] << (32u - jn) : 0u;  // first sphere of the word at bit 31
             if (sl[r].active) n_tests += jn;
-            while (cm) {  // per lane: its own candidate clusters
-                const uint32_t bit = static_cast<uint32_t>(__builtin_clz(cm));
-                cm &= ~(0x80000000u >> bit);
-                const uint32_t base = (g0 + bit) * kClusterStride;
-                const Path& p = sl[r].p;
-                uint32_t miss = 0u;
-#pragma unroll
-                for (uint32_t k = 0; k < kClusterSize; ++k) {
-                    const float4 s = slots[base + ((k + lane) & (kClusterSize - 1u))];
-                    const float ocx = p.o.x - s.x, ocy = p.o.y - s.y, ocz = p.o.z - s.z;
-                    const float hb = fma_(ocz, p.du.z, fma_(ocy, p.du.y, ocx * p.du.x));
-                    const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
-                    const float disc = fma_(hb, hb, -cc);
-                    miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(disc), 31);
-                }
-                n_tests += kClusterSize;
-                uint32_t cand = ~miss & 0xFFFFu;  // bit 15-k: member step k
-                while (cand) {
-                    const uint32_t k = static_cast<uint32_t>(__builtin_clz(cand)) - 16u;
-                    cand &= ~(0x8000u >> k);
-                    examine_keyed(slots, idx_map, base + ((k + lane) & (kClusterSize - 1u)), p, key[r], kslot[r]);
-                }
+            const Path& p = sl[r].p;
+            while (cand) {
+                const uint32_t bit = static_cast<uint32_t>(__builtin_clz(cand));
+                cand &= ~(0x80000000u >> bit);
+                examine_keyed(slots, idx_map, base + bit, p.o.x, p.o.y, p.o.z, p.du.x, p.du.y, p.du.z, key[r]);
             }
         }
     }
+    // ---- phases 1 and 2, 32 clusters at a time ----
+    for (uint32_t g0 = 0; g0 < a.n_clusters; g0 += 32u) {
+        uint32_t miss[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) miss[r] = 0u;
+        const uint32_t jn = a.n_clusters - g0 < 32u ? a.n_clusters - g0 : 32u;  // n_clusters is a multiple of 4
+#pragma unroll 4
+        for (uint32_t j = 0; j < jn; ++j) {
+            const float4 mid = bounds[2u * (g0 + j)], half = bounds[2u * (g0 + j) + 1u];  // LDS broadcast
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float tcx = fma_(mid.x, ix[r], ax[r]);
+                const float tcy = fma_(mid.y, iy[r], ay[r]);
+                const float tcz = fma_(mid.z, iz[r], az[r]);
+                const float jx = __builtin_fabsf(ix[r]), jy = __builtin_fabsf(iy[r]), jz = __builtin_fabsf(iz[r]);
+                // entry: latest of the three near planes and the origin; exit: earliest far plane
+                const float tn = __builtin_fmaxf(__builtin_fmaxf(fma_(-half.x, jx, tcx), fma_(-half.y, jy, tcy)),
+                                                 __builtin_fmaxf(fma_(-half.z, jz, tcz), 0.0f));
+                const float tf = __builtin_fminf(__builtin_fminf(fma_(half.x, jx, tcx), fma_(half.y, jy, tcy)),
+                                                 fma_(half.z, jz, tcz));
+                miss[r] = __builtin_amdgcn_alignbit(miss[r], __float_as_uint(tf - tn), 31);  // exit before entry
+            }
+        }
+        [[maybe_unused]] const unsigned long long ts0 = DBG_STAMP();
+        uint32_t cm[R];
+        uint32_t packed = 0u;  // candidate counts of the lane, 16 bits per slot (R == 2)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            cm[r] = sl[r].active ? (outside[r] ? ~0u : ~miss[r]) << (32u - jn) : 0u;  // first cluster at bit 31
+            if (sl[r].active) n_tests += jn;
+            packed |= static_cast<uint32_t>(__builtin_popcount(cm[r])) << (16 * r);
+            DBG_ADD(dbg_cands, __builtin_popcount(cm[r]));
+        }
+        uint32_t incl = packed;  // inclusive prefix sum over the lanes, both slots at once
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            incl += lane >= static_cast<uint32_t>(off) ? up : 0u;
+        }
+        const uint32_t totals = __builtin_amdgcn_readlane(incl, 63);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t total = (totals >> (16 * r)) & 0xFFFFu;
+            if (total == 0u) continue;
+            const Path& p = sl[r].p;
+            if (total > kItemCap) {
+                // (only when many rays start outside the boxes' range) each lane walks its own clusters
+                uint32_t m = cm[r];
+                while (m) {
+                    const uint32_t bit = static_cast<uint32_t>(__builtin_clz(m));
+                    m &= ~(0x80000000u >> bit);
+                    examine_cluster(slots, idx_map, a.n_large_slots + (g0 + bit) * kClusterStride, lane, p.o.x, p.o.y,
+                                    p.o.z, p.du.x, p.du.y, p.du.z, key[r]);
+                    n_tests += kClusterSize;
+                }
+                continue;
+            }
+            {   // my items, at my place in the list
+                uint32_t pos = ((incl - packed) >> (16 * r)) & 0xFFFFu;
+                uint32_t m = cm[r];
+                while (m) {
+                    const uint32_t bit = static_cast<uint32_t>(__builtin_clz(m));
+                    m &= ~(0x80000000u >> bit);
+                    items[pos++] = static_cast<uint16_t>(lane | (bit << 6));
+                }
+            }
+            // a wave's LDS operations are performed in order: the list is complete for the reads below
+            for (uint32_t k0 = 0; k0 < total; k0 += 64u) {
+                DBG_ADD(dbg_slow_trips, lane == 0u ? 1u : 0u);
+                const bool valid = k0 + lane < total;
+                const uint32_t item = valid ? items[k0 + lane] : 0u;
+                const int src = static_cast<int>(item & 63u);
+                const float ox = __shfl(p.o.x, src), oy = __shfl(p.o.y, src), oz = __shfl(p.o.z, src);
+                const float dx = __shfl(p.du.x, src), dy = __shfl(p.du.y, src), dz = __shfl(p.du.z, src);
+                if (valid) {
+                    unsigned long long k2 = ~0ull;
+                    examine_cluster(slots, idx_map, a.n_large_slots + (g0 + (item >> 6)) * kClusterStride, lane, ox, oy,
+                                    oz, dx, dy, dz, k2);
+                    n_tests += kClusterSize;
+                    if (k2 != ~0ull) atomicMin(&results[r * 64 + src], k2);  // ds_min_u64
+                }
+            }
+        }
+        DBG_ADD(dbg_t_slow, DBG_STAMP() - ts0);
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const bool hit = key[r] != ~0ull;
-        best[r] = hit ? __uint_as_float(static_cast<uint32_t>(key[r] >> 32)) : __builtin_inff();
-        best_i[r] = hit ? static_cast<int>(kslot[r]) : -1;
-        best_o[r] = static_cast<uint32_t>(key[r]);
+        const unsigned long long pooled = results[r * 64 + lane];
+        const unsigned long long k = pooled < key[r] ? pooled : key[r];
+        const bool hit = k != ~0ull;
+        best[r] = hit ? __uint_as_float(static_cast<uint32_t>(k >> 32)) : __builtin_inff();
+        best_i[r] = hit ? static_cast<int>(k & 0xFFFFu) : -1;
+        best_o[r] = static_cast<uint32_t>(k >> 16) & 0xFFFFu;
     }
 }
 
@@ -722,28 +842,37 @@ DI uint32_t lane_rank(unsigned long long mask) {  // number of set bits of mask 
                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
+#ifndef RTIOW_ACCEL_MAX_THREADS
+#define RTIOW_ACCEL_MAX_THREADS 512
+#endif
+constexpr int kAccelMaxThreads = RTIOW_ACCEL_MAX_THREADS;  // the clustered kernel wants ~166 VGPRs: groups of <= 512
+
 template <bool SHADE_LDS, bool ACCEL>
-__global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, PersistArgs g) {
+__global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persistent_kernel(PathArgs a, PersistArgs g) {
     // LDS: sphere list [g.n_pad float4] — the flat list, or (ACCEL) the clustered list's slots, then
-    // (ACCEL) the slots' original indices [g.n_pad u32] and the cluster bounds [a.n_clusters float4];
+    // (ACCEL) the slots' original indices [g.n_pad u32] and the cluster boxes [2 a.n_clusters float4];
     // then (SHADE_LDS) two float4 of shading record per sphere; then the accumulator entries of every
     // wave of the workgroup (a wave allocates only from its own 64); then the tail pool:
     // {parked, arrived, published, pad} + kTailPool records.
     extern __shared__ float4 lds_spheres[];
     uint32_t* lds_cidx = reinterpret_cast<uint32_t*>(lds_spheres + g.n_pad);
     float4* lds_cbounds = reinterpret_cast<float4*>(lds_cidx + (ACCEL ? g.n_pad : 0u));
-    float4* lds_shade = lds_cbounds + (ACCEL ? a.n_clusters : 0u);
+    float4* lds_shade = lds_cbounds + (ACCEL ? 2u * a.n_clusters : 0u);
     unsigned long long* lds_acc = reinterpret_cast<unsigned long long*>(lds_shade + (SHADE_LDS ? 2u * a.n : 0u));
     const uint32_t waves_in_group = blockDim.x / 64u;
     const uint32_t wave_in_group = threadIdx.x / 64u;
     uint32_t* lds_tail = reinterpret_cast<uint32_t*>(lds_acc + waves_in_group * (kWaveAccBytes / 8u));
+    // (ACCEL) per wave: the phase-2 work list and result keys of trace_clustered
+    [[maybe_unused]] unsigned long long* lds_results = reinterpret_cast<unsigned long long*>(
+        reinterpret_cast<unsigned char*>(lds_tail) + kTailBytes + wave_in_group * kWaveItemBytes);
+    [[maybe_unused]] uint16_t* lds_items = reinterpret_cast<uint16_t*>(lds_results + 128);
     if (threadIdx.x < 4u) lds_tail[threadIdx.x] = 0u;
     if (ACCEL) {
         for (uint32_t i = threadIdx.x; i < g.n_pad; i += blockDim.x) {
             lds_spheres[i] = a.cslots[i];
             lds_cidx[i] = a.cidx[i];
         }
-        for (uint32_t i = threadIdx.x; i < a.n_clusters; i += blockDim.x) lds_cbounds[i] = a.cbounds[i];
+        for (uint32_t i = threadIdx.x; i < 2u * a.n_clusters; i += blockDim.x) lds_cbounds[i] = a.cbounds[i];
     } else {
         stage_spheres(a, lds_spheres, g.n_pad);
     }
@@ -963,7 +1092,8 @@ __global__ __launch_bounds__(1024) void path_persistent_kernel(PathArgs a, Persi
                 if (sl[r].active) n_tests += ACCEL ? g.n_pad : a.n;
             DBG_ADD(dbg_sparse, lane == 0u ? 1u : 0u);
         } else if (ACCEL) {
-            trace_clustered<kSlots>(lds_spheres, lds_cidx, lds_cbounds, a.n_clusters, sl, best, best_i, best_o, n_tests);
+            trace_clustered<kSlots>(lds_spheres, lds_cidx, lds_cbounds, a, lds_items, lds_results, sl, best, best_i, best_o, n_tests,
+                                    dbg_slow_trips, dbg_cands, dbg_t_slow);
         } else {
             trace_slots<kSlots>(lds_spheres, g.n_pad, a.n, sl, best, best_i, dbg_slow_trips, dbg_cands, dbg_t_slow);
 #pragma unroll
@@ -1120,38 +1250,55 @@ hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, in
     }
     // default: the flat list (the north-star kernel) for scenes up to 1024 spheres, the clustered one
     // beyond (2.8x faster at 4096 spheres; frames are byte-identical either way)
-    const bool accel = kernel == KERNEL_CLUSTERED || (kernel == KERNEL_DEFAULT && a.n > 1024u);
+    bool accel = kernel == KERNEL_CLUSTERED || (kernel == KERNEL_DEFAULT && a.n > 1024u);
+    constexpr size_t kLdsPerCu = 160u * 1024u;
+    // the clustered list of the very largest scenes does not fit beside four waves' buffers: flat list then
+    if (accel && static_cast<size_t>(a.n_cslots) * 20u + static_cast<size_t>(a.n_clusters) * 32u +
+                         4u * (kWaveAccBytes + kWaveItemBytes) + kTailBytes > kLdsPerCu)
+        accel = false;
     PersistArgs g{};
     // slots of the LDS sphere list: the flat list padded to whole candidate words, or the clustered one
-    g.n_pad = accel ? a.n_clusters * kClusterStride : (a.n + kBlockSph - 1u) / kBlockSph * kBlockSph;
+    g.n_pad = accel ? a.n_cslots : (a.n + kBlockSph - 1u) / kBlockSph * kBlockSph;
     (void)max_take;  // scheduling is per sample now; the hint is accepted and ignored
     g.total_pix = a.local_rows * a.width;
     g.pool_pix = RTIOW_POOL_SAMPLES / a.spp;  // a few pixels per pool; one pixel when spp is large
     g.pool_pix = g.pool_pix < 1u ? 1u : (g.pool_pix > 256u ? 256u : g.pool_pix);
     // LDS per workgroup: the sphere list (16 B per slot; clustered: + 4 B per slot of indices and
-    // 16 B per cluster bound); while the scene is small, the shading records too (32 B each);
-    // 2 KiB of pixel accumulator entries per wave and the 7 KiB tail pool.
+    // 32 B per cluster box); while the scene is small, the shading records too (32 B each);
+    // 2 KiB of pixel accumulator entries per wave (clustered: + 3 KiB of work list and result keys) and
+    // the 7 KiB tail pool.
     const size_t lds_geo = static_cast<size_t>(g.n_pad) * sizeof(float4) +
-                           (accel ? static_cast<size_t>(g.n_pad) * 4u + static_cast<size_t>(a.n_clusters) * 16u : 0u);
+                           (accel ? static_cast<size_t>(g.n_pad) * 4u + static_cast<size_t>(a.n_clusters) * 32u : 0u);
     const bool shade_lds = lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 28u * 1024u;
     const size_t lds_scene = lds_geo + (shade_lds ? static_cast<size_t>(a.n) * sizeof(ShadeRec) : 0u);
-    // small scenes -> 256-thread groups; large ones -> 1024-thread groups so 16 waves share one copy
-    // (a very large list leaves room for 8 waves' accumulators only: 512 threads)
-    uint32_t threads = lds_scene <= 28u * 1024u ? 256u : 1024u;
-    constexpr size_t kLdsPerCu = 160u * 1024u;
-    if (lds_scene + static_cast<size_t>(threads / 64u) * kWaveAccBytes + kTailBytes > kLdsPerCu) threads = 512u;
-    const size_t lds = lds_scene + static_cast<size_t>(threads / 64u) * kWaveAccBytes + kTailBytes;
-    if (lds > kLdsPerCu) return hipErrorInvalidValue;  // rtSetScene's sphere limit keeps this from happening
+    const size_t lds_wave = kWaveAccBytes + (accel ? kWaveItemBytes : 0u);
     void (*kernel_fn)(PathArgs, PersistArgs) =
         accel ? (shade_lds ? path_persistent_kernel<true, true> : path_persistent_kernel<false, true>)
               : (shade_lds ? path_persistent_kernel<true, false> : path_persistent_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_fn),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsPerCu));
     if (e != hipSuccess) return e;
+    // Workgroup size: the one that keeps the most waves on a CU (the waves of a group share one copy of
+    // the scene, so small scenes do best with 256-thread groups and large ones with 1024); ties go to
+    // the smaller group.  RTIOW_DEBUG_THREADS pins it (tuning only).
+    uint32_t threads = 0u;
     int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel_fn, static_cast<int>(threads), lds);
-    if (e != hipSuccess) return e;
-    if (per_cu < 1) per_cu = 1;
+    size_t lds = 0u;
+    const uint32_t pinned = getenv("RTIOW_DEBUG_THREADS") ? strtoul(getenv("RTIOW_DEBUG_THREADS"), nullptr, 10) : 0u;
+    for (uint32_t t = 256u; t <= (accel ? static_cast<uint32_t>(kAccelMaxThreads) : 1024u); t *= 2u) {
+        if (pinned != 0u && t != pinned) continue;
+        const size_t need = lds_scene + static_cast<size_t>(t / 64u) * lds_wave + kTailBytes;
+        if (need > kLdsPerCu) continue;
+        int blocks = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel_fn, static_cast<int>(t), need);
+        if (e != hipSuccess) return e;
+        if (blocks * static_cast<int>(t) > per_cu * static_cast<int>(threads)) {
+            threads = t;
+            per_cu = blocks;
+            lds = need;
+        }
+    }
+    if (threads == 0u) return hipErrorInvalidValue;  // rtSetScene's sphere limit keeps this from happening
     // persistent grid: fill the chip once; never more slots than samples
     unsigned long long grid = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256) * per_cu;
     const unsigned long long samples = static_cast<unsigned long long>(g.total_pix) * a.spp;
