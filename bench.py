@@ -25,7 +25,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FLOPS_PER_TEST = 16             # oc 3, hb 5, cc 6, disc 2 (unit direction: a == 1)
 FLOPS_PER_SEGMENT_SHADE = 60
 
-KERNEL_NAMES = {0: "persistent_flat_list", 1: "pixel_per_lane", 2: "persistent_flat_list", 3: "persistent_clustered_list"}
+KERNEL_NAMES = {1: "pixel_per_lane", 2: "persistent_flat_list", 3: "persistent_clustered_list"}
 
 WORKLOADS = {
     # name: (scene, grid_half, width, height, spp, depth)
@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--chunk-spp", type=int, default=10)
     ap.add_argument("--row-block", type=int, default=4)
     ap.add_argument("--kernel", type=int, default=0,
-                    help="0/2 persistent flat list (the north-star kernel), 3 persistent clustered list, 1 one lane per pixel")
+                    help="0 library default (clustered list from 64 spheres on), 2 persistent flat list, 3 persistent clustered list, 1 one lane per pixel")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames rendered concurrently on separate contexts/streams, as the reference keeps one "
                          "compute fence per swapchain image (RTCHAP06/main.cpp:94-98,313-316); 0 = auto: 1 on one "
@@ -212,19 +212,23 @@ def main():
         nominal = w * h * spp * depth
         value = nominal / (elapsed / args.steps) / 1e6
         n = len(sph)
-        eff_kernel = args.kernel if args.kernel else (3 if n > 1024 else 2)   # what kernel 0 resolves to
-        # dominant kernel: the path-trace kernel of rank 0's tile (per launch); flops from the tests the
-        # kernel actually performed (flat list: segments * N; clustered list: bounds + members visited)
-        flops = st.sphere_tests * FLOPS_PER_TEST + st.segments * FLOPS_PER_SEGMENT_SHADE
+        eff_kernel = ctx.last_kernel()   # what RtParams.kernel 0 resolved to
+        # dominant kernel: the path-trace kernel of rank 0's tile (per launch).  Algorithmic flops per
+        # every segment against the whole hittable list, segments * (16 N + 60) -- the work
+        # the north-star algorithm defines, whichever kernel ran.  The clustered kernel reaches the same
+        # hits with fewer tests; what it executed is reported beside it.
+        flops = st.segments * (n * FLOPS_PER_TEST + FLOPS_PER_SEGMENT_SHADE)
         achieved = flops / (kernel_ms * 1e-3) / 1e12
+        executed = (st.sphere_tests * FLOPS_PER_TEST + st.segments * FLOPS_PER_SEGMENT_SHADE) / (kernel_ms * 1e-3) / 1e12
         fb_bytes = st.bytes_written
         traffic = None
-        tname = "traffic_r*c.json" if eff_kernel == 3 else "traffic_r[0-9][0-9].json"
-        tpath = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", tname)) or [""])[-1]
-        if world == 1 and tpath and os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("workload") == args.workload and tj.get("bench_kernel") == KERNEL_NAMES.get(eff_kernel):
-                traffic = tj.get("hbm_bytes_per_launch")
+        if world == 1:  # PMC traffic of this workload + kernel, newest profile first
+            for tpath in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "traffic_*.json")),
+                                key=os.path.getmtime, reverse=True):
+                tj = json.load(open(tpath))
+                if tj.get("workload") == args.workload and tj.get("bench_kernel") == KERNEL_NAMES.get(eff_kernel):
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    break
         out = {
             "metric": "Mray/s (w*h*spp*depth / s), cover scene 1200x800", "value": value, "unit": "Mray/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -243,8 +247,12 @@ def main():
                 "bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": traffic,
                 "note": "fp32 vector-ALU bound (no dense contraction: MFMA unused by design); algorithmic "
-                        f"flops = tests*{FLOPS_PER_TEST} + segments*{FLOPS_PER_SEGMENT_SHADE} (flat list: tests = "
-                        "segments*N), kernel time = HIP events on the launch stream over the timed steps",
+                        f"flops (SURVEY 8d) = segments*(N*{FLOPS_PER_TEST} + {FLOPS_PER_SEGMENT_SHADE}): every segment "
+                        "against the whole hittable list; kernel time = HIP events on the launch stream over the "
+                        "timed steps.  `executed` counts the tests the kernel really made (the clustered list "
+                        "skips most of them, so its algorithmic rate is not a VALU utilisation)",
+                "executed": {"achieved": executed, "frac": executed / FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "tests_per_segment": st.sphere_tests / max(1, st.segments)},
                 "hbm_write": {"achieved": fb_bytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": fb_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "bytes_per_launch": fb_bytes},

@@ -170,6 +170,12 @@ int rtRenderUbo(RtContext* ctx, const RtUbo5* ubo, uint32_t mode, void* dst, siz
 int rtGetStats(RtContext* ctx, RtStats* out);
 int rtSynchronize(RtContext* ctx);
 
+/* Which kernel variant the last RT_MODE_PATH render ran (RtParams.kernel 0 lets the library choose):
+ * 1 one lane per pixel, 2 persistent waves over the flat list, 3 persistent waves over the clustered
+ * list.  All variants produce the same bytes.  Diagnostic; no reference counterpart (the reference
+ * has one pipeline, RTCHAP06/main.cpp:153-157). */
+int rtGetLastKernel(RtContext* ctx, uint32_t* kernel_out);
+
 /* Arithmetic conformance probe (diagnostic): evaluates one operation per
  * element on the GPU over host arrays — op 0 fma(a,b,c), 1 a/b, 2 sqrt(a),
  * 3 a*b, 4 a+b, 5 RNG draw, 6 fixed-point accumulate, 7 u64->float — so a CPU/GPU rounding difference can be pinned to

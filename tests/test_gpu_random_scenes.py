@@ -51,3 +51,54 @@ def test_random_scene_all_kernels(gpu_ctx, oracle, case):
         bad = int((got != want).any(axis=2).sum())
         assert bad == 0, (case, kernel, n, scale, dist, bad)
         assert st.segments == segs, (case, kernel)
+
+
+def test_default_kernel_choice(gpu_ctx):
+    """RtParams.kernel 0: clustered list from 64 spheres on, flat list for small scenes and for a camera
+    outside the range the cluster boxes were sized for; an explicit choice is honoured."""
+    sph, mat = V.make_cover_scene(1, 11)
+    gpu_ctx.set_scene(sph, mat)
+    near = V.make_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, 1.5, 0.1, 10.0)
+    far = V.make_camera((1300, 200, 300), (0, 0, 0), (0, 1, 0), 1.0, 1.5, 0.0, 10.0)
+    prm = dict(spp=1, max_depth=4, seed=3)
+    a = gpu_ctx.render(near, V.make_params(48, 32, **prm))
+    assert gpu_ctx.last_kernel() == V.KERNEL_CLUSTERED
+    b = gpu_ctx.render(near, V.make_params(48, 32, kernel=V.KERNEL_PERSISTENT, **prm))
+    assert gpu_ctx.last_kernel() == V.KERNEL_PERSISTENT and np.array_equal(a, b)
+    gpu_ctx.render(near, V.make_params(48, 32, kernel=V.KERNEL_PIXEL, **prm))
+    assert gpu_ctx.last_kernel() == V.KERNEL_PIXEL
+    gpu_ctx.render(far, V.make_params(48, 32, **prm))
+    assert gpu_ctx.last_kernel() == V.KERNEL_PERSISTENT
+    sph3, mat3 = V.make_three_sphere_scene()
+    gpu_ctx.set_scene(sph3, mat3)
+    gpu_ctx.render(V.make_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 90.0, 1.5, 0.0, 1.0), V.make_params(48, 32, **prm))
+    assert gpu_ctx.last_kernel() == V.KERNEL_PERSISTENT
+
+
+@pytest.mark.parametrize("n", [40, 330])
+def test_rays_from_outside_the_box_range(gpu_ctx, oracle, n):
+    """A tight knot of spheres on a huge ground, wide camera: most bounces start on the ground far
+    outside the range the cluster boxes are inflated for (2 scene diagonals) and must walk every
+    cluster; with 330 spheres a wave's pooled work list overflows and each lane walks its own."""
+    rng = np.random.default_rng(77 + n)
+    sph = np.zeros(n + 1, V.SPHERE_DTYPE)
+    mat = np.zeros(n + 1, V.MATERIAL_DTYPE)
+    sph["cx"][1:] = rng.uniform(-1, 1, n)
+    sph["cy"][1:] = rng.uniform(0.1, 2.0, n)
+    sph["cz"][1:] = rng.uniform(-1, 1, n)
+    sph["radius"][1:] = rng.uniform(0.03, 0.12, n)
+    kinds = rng.choice([0, 1, 2], n, p=[0.5, 0.3, 0.2])
+    mat["kind"][1:] = kinds
+    mat["albedo"][1:] = rng.uniform(0.3, 1.0, (n, 3))
+    mat["ior"][1:] = np.where(kinds == 2, 1.5, 0)
+    sph[0] = (0.0, -1000.0, 0.0, 1000.0)
+    mat[0] = (1, (0.9, 0.9, 0.9), 0.05, 0.0, (0, 0))        # a mirror-like floor sends rays back up to the knot
+    cam = V.make_camera((3.5, 1.5, 3.0), (0, 0.5, 0), (0, 1, 0), 100.0, 4 / 3, 0.0, 1.0)
+    w, h = 96, 72
+    base = dict(spp=6, max_depth=12, seed=5)
+    want, segs = oracle.render(sph, mat, cam, V.make_params(w, h, **base))
+    gpu_ctx.set_scene(sph, mat)
+    got = gpu_ctx.render(cam, V.make_params(w, h, kernel=V.KERNEL_CLUSTERED, **base))
+    assert gpu_ctx.last_kernel() == V.KERNEL_CLUSTERED
+    st = gpu_ctx.stats()
+    assert int((got != want).any(axis=2).sum()) == 0 and st.segments == segs

@@ -19,6 +19,8 @@ libs = []
 for path in args:
     lib = C.CDLL(os.path.abspath(path))
     for name, (res, at) in api.SIGNATURES.items():
+        if not hasattr(lib, name):
+            continue  # an older build
         getattr(lib, name).restype = res
         getattr(lib, name).argtypes = at
     h_ = C.c_void_p()

@@ -78,6 +78,7 @@ SIGNATURES = {
     "rtRenderUbo": (C.c_int, [_VP, C.POINTER(RtUbo5), C.c_uint32, _VP, C.c_size_t, C.c_int, _VP]),
     "rtGetStats": (C.c_int, [_VP, C.POINTER(RtStats)]),
     "rtSynchronize": (C.c_int, [_VP]),
+    "rtGetLastKernel": (C.c_int, [_VP, C.POINTER(C.c_uint32)]),
     "rtSelfTestArith": (C.c_int, [_VP, C.c_uint32, _VP, _VP, _VP, _VP, C.c_uint32]),
     "rtUboFromImage": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(RtUbo5)]),
     "rtCameraFromUbo": (C.c_int, [C.POINTER(RtUbo5), C.POINTER(RtCamera)]),
@@ -260,6 +261,12 @@ class Context:
         st = RtStats()
         _check(self._h, self._lib.rtGetStats(self._h, C.byref(st)), "rtGetStats")
         return st
+
+    def last_kernel(self) -> int:
+        """Kernel variant the last PATH render launched (KERNEL_PIXEL / _PERSISTENT / _CLUSTERED)."""
+        k = C.c_uint32(0)
+        _check(self._h, self._lib.rtGetLastKernel(self._h, C.byref(k)), "rtGetLastKernel")
+        return int(k.value)
 
     def selftest_arith(self, op: int, a: np.ndarray, b: np.ndarray, c: np.ndarray) -> np.ndarray:
         a = np.ascontiguousarray(a, np.float32)

@@ -27,6 +27,7 @@ struct RtContext {
     uint32_t n_clusters = 0, n_large = 0, n_large_slots = 0, n_cslots = 0;
     float cluster_center[3] = {0, 0, 0};
     float cluster_diag = 0, cluster_rmax2 = 0;
+    uint32_t last_kernel = 0;     // variant the last PATH render launched
     uint32_t n_spheres = 0;
     rtiow::Counters* d_counters = nullptr;
     rtiow::Counters* h_counters = nullptr;  // pinned
@@ -320,7 +321,7 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
             const double reach = 1.9 * double(ctx->cluster_diag) - double(cam->lens_radius);
             if (!(reach > 0.0 && d2 <= reach * reach)) kernel = rtiow::KERNEL_PERSISTENT;
         }
-        RT_HIP(ctx, rtiow::launch_path(a, kernel, prm->chunk_spp, ctx->num_cus, stream));
+        RT_HIP(ctx, rtiow::launch_path(a, kernel, prm->chunk_spp, ctx->num_cus, stream, &ctx->last_kernel));
     }
     RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream));
     RT_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(rtiow::Counters),
@@ -402,6 +403,13 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
         for (int k = 0; k < 8; ++k) ctx->stats.debug[k] = ctx->h_counters->debug[k];
     }
     *out = ctx->stats;
+    return RT_OK;
+}
+
+int rtGetLastKernel(RtContext* ctx, uint32_t* kernel_out) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rtGetLastKernel: ctx is null");
+    if (!kernel_out) return fail(ctx, RT_ERR_INVALID, "rtGetLastKernel: kernel_out is null");
+    *kernel_out = ctx->last_kernel;
     return RT_OK;
 }
 

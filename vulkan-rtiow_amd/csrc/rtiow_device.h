@@ -93,8 +93,9 @@ enum : uint32_t {
 };
 
 hipError_t launch_ch(const ChArgs& a, hipStream_t stream);
+// `resolved` receives the variant that was launched (KERNEL_DEFAULT resolves to one of the others)
 hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, int num_cus,
-                       hipStream_t stream);
+                       hipStream_t stream, uint32_t* resolved);
 hipError_t launch_arith(uint32_t op, const float* a, const float* b, const float* c, float* out,
                         uint32_t n, hipStream_t stream);
 

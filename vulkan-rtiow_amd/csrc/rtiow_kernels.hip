@@ -671,6 +671,18 @@ DI void examine_cluster(const float4* slots, const uint32_t* idx_map, uint32_t b
     }
 }
 
+// Inclusive prefix sum over the 64 lanes on the DPP network (no LDS round trips): Hillis-Steele inside
+// each row of 16 lanes, then the last lane of row 0/2 into row 1/3 and of row 1 into rows 2-3.
+DI uint32_t wave_inclusive_sum(uint32_t v) {
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, true));  // row_shr:1
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xf, 0xf, true));  // row_shr:2
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, true));  // row_shr:4
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xf, 0xf, true));  // row_shr:8
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xa, 0xf, false)); // row_bcast:15
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xc, 0xf, false)); // row_bcast:31
+    return v;
+}
+
 DI float slab_rcp(float d) {  // reciprocal of a direction component kept away from zero (finite slabs, no NaN)
     const float c = __builtin_fabsf(d) < 1e-18f ? __builtin_copysignf(1e-18f, d) : d;
     return __builtin_amdgcn_rcpf(c);
@@ -774,12 +786,7 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
             packed |= static_cast<uint32_t>(__builtin_popcount(cm[r])) << (16 * r);
             DBG_ADD(dbg_cands, __builtin_popcount(cm[r]));
         }
-        uint32_t incl = packed;  // inclusive prefix sum over the lanes, both slots at once
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t up = __shfl_up(incl, off);
-            incl += lane >= static_cast<uint32_t>(off) ? up : 0u;
-        }
+        const uint32_t incl = wave_inclusive_sum(packed);  // over the lanes, both slots at once
         const uint32_t totals = __builtin_amdgcn_readlane(incl, 63);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -1234,10 +1241,12 @@ hipError_t launch_ch(const ChArgs& a, hipStream_t stream) {
 }
 
 static bool use_persistent(uint32_t kernel) { return kernel != KERNEL_PIXEL; }
+constexpr uint32_t kClusteredFrom = 64;  // spheres; below, boxes + one cluster cost more than the flat scan
 
 hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, int num_cus,
-                       hipStream_t stream) {
+                       hipStream_t stream, uint32_t* resolved) {
     if (!use_persistent(kernel)) {
+        *resolved = KERNEL_PIXEL;
         const uint32_t tiles = ((a.width + 15u) / 16u) * ((a.local_rows + 15u) / 16u);
         const size_t lds = static_cast<size_t>(a.n) * sizeof(float4);
         if (lds > 48u * 1024u) {
@@ -1248,14 +1257,15 @@ hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, in
         hipLaunchKernelGGL(path_pixel_kernel, dim3(tiles), dim3(256), lds, stream, a);
         return hipGetLastError();
     }
-    // default: the flat list (the north-star kernel) for scenes up to 1024 spheres, the clustered one
-    // beyond (2.8x faster at 4096 spheres; frames are byte-identical either way)
-    bool accel = kernel == KERNEL_CLUSTERED || (kernel == KERNEL_DEFAULT && a.n > 1024u);
+    // default: the clustered list from kClusteredFrom spheres on (cover scene: 2.1x faster than the
+    // flat list; frames are byte-identical either way), the flat list for the handful-of-spheres scenes
+    bool accel = kernel == KERNEL_CLUSTERED || (kernel == KERNEL_DEFAULT && a.n >= kClusteredFrom);
     constexpr size_t kLdsPerCu = 160u * 1024u;
     // the clustered list of the very largest scenes does not fit beside four waves' buffers: flat list then
     if (accel && static_cast<size_t>(a.n_cslots) * 20u + static_cast<size_t>(a.n_clusters) * 32u +
                          4u * (kWaveAccBytes + kWaveItemBytes) + kTailBytes > kLdsPerCu)
         accel = false;
+    *resolved = accel ? KERNEL_CLUSTERED : KERNEL_PERSISTENT;
     PersistArgs g{};
     // slots of the LDS sphere list: the flat list padded to whole candidate words, or the clustered one
     g.n_pad = accel ? a.n_cslots : (a.n + kBlockSph - 1u) / kBlockSph * kBlockSph;
