@@ -689,7 +689,7 @@ DI float slab_rcp(float d) {  // reciprocal of a direction component kept away f
 }
 
 // Per-wave LDS of the clustered trace: the work list of phase 2 and the per-ray results.
-constexpr uint32_t kItemCap = 512;                          // (ray, cluster) items per slot and group of 32 clusters
+constexpr uint32_t kItemCap = 512;                          // (ray, cluster) items per group of 32 clusters
 constexpr uint32_t kWaveItemBytes = kItemCap * 2u + 128u * 8u;  // u16 items + one u64 key per path slot
 
 // Phase 2 is where rays diverge: a ray reaches 3 clusters on average, the unluckiest of a wave's 64
@@ -778,23 +778,22 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
         }
         [[maybe_unused]] const unsigned long long ts0 = DBG_STAMP();
         uint32_t cm[R];
-        uint32_t packed = 0u;  // candidate counts of the lane, 16 bits per slot (R == 2)
+        uint32_t packed = 0u;  // candidate clusters of the lane, both slots
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             cm[r] = sl[r].active ? (outside[r] ? ~0u : ~miss[r]) << (32u - jn) : 0u;  // first cluster at bit 31
             if (sl[r].active) n_tests += jn;
-            packed |= static_cast<uint32_t>(__builtin_popcount(cm[r])) << (16 * r);
+            packed += static_cast<uint32_t>(__builtin_popcount(cm[r]));
             DBG_ADD(dbg_cands, __builtin_popcount(cm[r]));
         }
-        const uint32_t incl = wave_inclusive_sum(packed);  // over the lanes, both slots at once
-        const uint32_t totals = __builtin_amdgcn_readlane(incl, 63);
+        const uint32_t incl = wave_inclusive_sum(packed);  // over the lanes
+        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+        if (total == 0u) continue;
+        if (total > kItemCap) {
+            // (only when many rays start outside the boxes' range) each lane walks its own clusters
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t total = (totals >> (16 * r)) & 0xFFFFu;
-            if (total == 0u) continue;
-            const Path& p = sl[r].p;
-            if (total > kItemCap) {
-                // (only when many rays start outside the boxes' range) each lane walks its own clusters
+            for (int r = 0; r < R; ++r) {
+                const Path& p = sl[r].p;
                 uint32_t m = cm[r];
                 while (m) {
                     const uint32_t bit = static_cast<uint32_t>(__builtin_clz(m));
@@ -803,32 +802,40 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
                                     p.o.z, p.du.x, p.du.y, p.du.z, key[r]);
                     n_tests += kClusterSize;
                 }
-                continue;
             }
-            {   // my items, at my place in the list
-                uint32_t pos = ((incl - packed) >> (16 * r)) & 0xFFFFu;
+            continue;
+        }
+        {   // my items, at my place in the list: lane | slot << 6 | cluster-in-group << 7
+            uint32_t pos = incl - packed;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
                 uint32_t m = cm[r];
                 while (m) {
                     const uint32_t bit = static_cast<uint32_t>(__builtin_clz(m));
                     m &= ~(0x80000000u >> bit);
-                    items[pos++] = static_cast<uint16_t>(lane | (bit << 6));
+                    items[pos++] = static_cast<uint16_t>(lane | (static_cast<uint32_t>(r) << 6) | (bit << 7));
                 }
             }
-            // a wave's LDS operations are performed in order: the list is complete for the reads below
-            for (uint32_t k0 = 0; k0 < total; k0 += 64u) {
-                DBG_ADD(dbg_slow_trips, lane == 0u ? 1u : 0u);
-                const bool valid = k0 + lane < total;
-                const uint32_t item = valid ? items[k0 + lane] : 0u;
-                const int src = static_cast<int>(item & 63u);
-                const float ox = __shfl(p.o.x, src), oy = __shfl(p.o.y, src), oz = __shfl(p.o.z, src);
-                const float dx = __shfl(p.du.x, src), dy = __shfl(p.du.y, src), dz = __shfl(p.du.z, src);
-                if (valid) {
-                    unsigned long long k2 = ~0ull;
-                    examine_cluster(slots, idx_map, a.n_large_slots + (g0 + (item >> 6)) * kClusterStride, lane, ox, oy,
-                                    oz, dx, dy, dz, k2);
-                    n_tests += kClusterSize;
-                    if (k2 != ~0ull) atomicMin(&results[r * 64 + src], k2);  // ds_min_u64
-                }
+        }
+        // a wave's LDS operations are performed in order: the list is complete for the reads below
+        for (uint32_t k0 = 0; k0 < total; k0 += 64u) {
+            DBG_ADD(dbg_slow_trips, lane == 0u ? 1u : 0u);
+            const bool valid = k0 + lane < total;
+            const uint32_t item = valid ? items[k0 + lane] : 0u;
+            const int src = static_cast<int>(item & 63u);
+            const bool second = (item & 64u) != 0u;
+            static_assert(R == 2, "the work list encodes the path slot in one bit");
+            const float ox0 = __shfl(sl[0].p.o.x, src), oy0 = __shfl(sl[0].p.o.y, src), oz0 = __shfl(sl[0].p.o.z, src);
+            const float dx0 = __shfl(sl[0].p.du.x, src), dy0 = __shfl(sl[0].p.du.y, src), dz0 = __shfl(sl[0].p.du.z, src);
+            const float ox1 = __shfl(sl[1].p.o.x, src), oy1 = __shfl(sl[1].p.o.y, src), oz1 = __shfl(sl[1].p.o.z, src);
+            const float dx1 = __shfl(sl[1].p.du.x, src), dy1 = __shfl(sl[1].p.du.y, src), dz1 = __shfl(sl[1].p.du.z, src);
+            if (valid) {
+                unsigned long long k2 = ~0ull;
+                examine_cluster(slots, idx_map, a.n_large_slots + (g0 + (item >> 7)) * kClusterStride, lane,
+                                second ? ox1 : ox0, second ? oy1 : oy0, second ? oz1 : oz0, second ? dx1 : dx0,
+                                second ? dy1 : dy0, second ? dz1 : dz0, k2);
+                n_tests += kClusterSize;
+                if (k2 != ~0ull) atomicMin(&results[(item & 127u)], k2);  // ds_min_u64; slot * 64 + lane
             }
         }
         DBG_ADD(dbg_t_slow, DBG_STAMP() - ts0);
