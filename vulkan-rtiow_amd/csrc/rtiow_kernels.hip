@@ -1286,7 +1286,8 @@ hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, in
     // the 7 KiB tail pool.
     const size_t lds_geo = static_cast<size_t>(g.n_pad) * sizeof(float4) +
                            (accel ? static_cast<size_t>(g.n_pad) * 4u + static_cast<size_t>(a.n_clusters) * 32u : 0u);
-    const bool shade_lds = lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 28u * 1024u;
+    const bool shade_lds = lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 28u * 1024u &&
+                           !getenv("RTIOW_DEBUG_NO_SHADE_LDS");  // (tuning only)
     const size_t lds_scene = lds_geo + (shade_lds ? static_cast<size_t>(a.n) * sizeof(ShadeRec) : 0u);
     const size_t lds_wave = kWaveAccBytes + (accel ? kWaveItemBytes : 0u);
     void (*kernel_fn)(PathArgs, PersistArgs) =
