@@ -401,6 +401,17 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
         ctx->stats.sphere_tests = ctx->h_counters->tests ? ctx->h_counters->tests
                                                          : ctx->stats.segments * ctx->stats.n_spheres;
         for (int k = 0; k < 8; ++k) ctx->stats.debug[k] = ctx->h_counters->debug[k];
+        if (getenv("RTIOW_DEBUG_HIST")) {  // diagnostic builds: when waves ran dry / finished, 0.125 ms bins
+            fprintf(stderr, "waves dry :");
+            for (int k = 0; k < 32; ++k) fprintf(stderr, " %u", ctx->h_counters->hist_dry[k]);
+            fprintf(stderr, "\nwaves done:");
+            for (int k = 0; k < 32; ++k) fprintf(stderr, " %u", ctx->h_counters->hist_end[k]);
+            const rtiow::Counters& c = *ctx->h_counters;
+            fprintf(stderr, "\ntail: %llu iterations, %.2f us each; sparse among them %llu, trace %.2f us each, %.1f paths each\n",
+                    c.tail_iters, c.tail_iters ? c.tail_ticks * 0.01 / c.tail_iters : 0.0, c.tail_sparse_iters,
+                    c.tail_sparse_iters ? c.tail_sparse_ticks * 0.01 / c.tail_sparse_iters : 0.0,
+                    c.tail_sparse_iters ? double(c.tail_sparse_paths) / c.tail_sparse_iters : 0.0);
+        }
     }
     *out = ctx->stats;
     return RT_OK;

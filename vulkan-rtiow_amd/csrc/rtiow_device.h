@@ -16,6 +16,11 @@ struct Counters {
     unsigned int xcd_head[8];       // persistent kernel: heads of the eight per-XCD pixel queues
     unsigned long long tests;       // ray-sphere and ray-bound tests performed
     unsigned long long debug[8];    // diagnostic builds (-DRTIOW_DEBUG_COUNTERS) only
+    unsigned long long not_t0;      // diagnostic builds: ~(earliest wave start), 100 MHz ticks
+    unsigned int hist_dry[32];      // diagnostic builds: waves by the time their queue ran dry, 0.125 ms bins
+    unsigned int hist_end[32];      // diagnostic builds: waves by the time they finished
+    unsigned long long tail_iters, tail_ticks;  // diagnostic builds: iterations / 100 MHz ticks of all waves after running dry
+    unsigned long long tail_sparse_iters, tail_sparse_ticks, tail_sparse_paths;  // the sparse ones among them
 };
 
 // Device-side shading record of one sphere (32 B), built by rtSetScene from RtSphere + RtMaterial.

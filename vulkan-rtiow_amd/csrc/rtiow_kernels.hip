@@ -444,8 +444,18 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 // sphere's first root in (t_min, inf), ties to the lowest index — exactly what
 // the oracle's sequential scan computes.
 
+// Samples a wave takes from its queue at a time.  A fetch costs two dependent atomics on a head that
+// thousands of waves share (microseconds, during which the wave's idle lanes wait), so pools must last a
+// few iterations; too large and the end of the frame balances badly.  Measured (tools/ab_bench.py, cover
+// frame): flat list 100 -> 36.3 ms, 200 -> 31.3, 300..768 -> 29.8-30.5, 2048 -> 32.6; clustered list
+// (2.6x fewer cycles per sample) 128 -> 35.0, 256 -> 19.0, 384 -> 14.2, 768 -> 12.0, 1536 -> 11.4,
+// 3072 -> 11.9.  Asking for the next pool ahead of time (one atomic in flight per wave) reaches the same
+// 11.5 ms at any pool size but costs the flat list 2 ms in registers: not used.
 #ifndef RTIOW_POOL_SAMPLES
-#define RTIOW_POOL_SAMPLES 384u  // measured (tools/ab_bench.py): 100 -> 36.3 ms, 200 -> 31.3, 300..512 -> 29.8, 2048 -> 32.6
+#define RTIOW_POOL_SAMPLES 384u
+#endif
+#ifndef RTIOW_POOL_SAMPLES_ACCEL
+#define RTIOW_POOL_SAMPLES_ACCEL 1536u
 #endif
 constexpr int kSlots = 2;           // path slots per lane
 constexpr uint32_t kBlockSph = 32;  // spheres per candidate word
@@ -453,6 +463,11 @@ constexpr uint32_t kBlockSph = 32;  // spheres per candidate word
 #define RTIOW_SPARSE_MAX 16
 #endif
 constexpr uint32_t kSparseMax = RTIOW_SPARSE_MAX; // live paths per wave at or below which the sphere-parallel trace runs
+#ifndef RTIOW_SPARSE_MAX_ACCEL
+#define RTIOW_SPARSE_MAX_ACCEL 10  // measured 6..16: equal within noise; ~1 us per path against ~8 us for a lone dense iteration
+#endif
+constexpr uint32_t kSparseMaxAccel = RTIOW_SPARSE_MAX_ACCEL;  // the same for the clustered list (cluster-parallel trace)
+constexpr uint32_t kDonateMax = 16;  // live paths at or below which a wave parks them in the workgroup's tail pool
 constexpr uint32_t kTailPool = 112; // paths a workgroup's tail pool holds (the adopter keeps <= 16 of its own)
 constexpr uint32_t kTailRecWords = 16;  // 64-byte parked-path records
 constexpr uint32_t kTailBytes = 16u + kTailPool * kTailRecWords * 4u;  // counters + records
@@ -851,6 +866,103 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
     }
 }
 
+// Minimum over the 64 lanes on the DPP network (row scans, then row 0/2 -> 1/3 and row 1 -> 2-3);
+// the result is read from lane 63.
+template <int CTRL, int ROW_MASK>
+DI uint32_t dpp_min_step(uint32_t x) {  // lanes the DPP pattern leaves without a source keep x
+    const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(-1, static_cast<int>(x), CTRL, ROW_MASK, 0xf, false));
+    return o < x ? o : x;
+}
+DI uint32_t wave_min_u32(uint32_t v) {
+    v = dpp_min_step<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_min_step<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_min_step<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_min_step<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_min_step<0x142, 0xa>(v);  // row_bcast:15
+    v = dpp_min_step<0x143, 0xc>(v);  // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Cluster-parallel closest hit for a wave with few live paths (the end of a frame: what is left are the
+// long paths, one dependent segment after another, so the latency of an iteration is what counts).  One
+// path at a time, its ray in SGPRs: every lane takes one large sphere (exact test) and one cluster box;
+// the boxes the ray reaches come back as a ballot and their members are tested four clusters at a time,
+// one member per lane; the hit is the wave minimum of the packed key.  Same tests, same key, same
+// result as trace_clustered.
+template <int R>
+DI void trace_sparse_clustered(const float4* slots, const uint32_t* idx_map, const float4* bounds, const PathArgs& a,
+                               Slot (&sl)[R], float (&best)[R], int (&best_i)[R], uint32_t (&best_o)[R],
+                               uint32_t& n_tests) {
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        best[r] = __builtin_inff();
+        best_i[r] = -1;
+        best_o[r] = 0u;
+        unsigned long long live = __ballot(sl[r].active);
+        while (live != 0ull) {
+            const int src = __builtin_ctzll(live);
+            live &= live - 1ull;
+            const Path& p = sl[r].p;
+            const float ox = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.o.x), src));
+            const float oy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.o.y), src));
+            const float oz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.o.z), src));
+            const float dx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.du.x), src));
+            const float dy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.du.y), src));
+            const float dz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.du.z), src));
+            unsigned long long key = ~0ull;
+            for (uint32_t j = lane; j < a.n_large; j += 64u) {
+                examine_keyed(slots, idx_map, j, ox, oy, oz, dx, dy, dz, key);
+                ++n_tests;
+            }
+            const float ix = slab_rcp(dx), iy = slab_rcp(dy), iz = slab_rcp(dz);
+            const float ax = -ox * ix, ay = -oy * iy, az = -oz * iz;
+            const float jx = __builtin_fabsf(ix), jy = __builtin_fabsf(iy), jz = __builtin_fabsf(iz);
+            const float qx = ox - a.ccenter[0], qy = oy - a.ccenter[1], qz = oz - a.ccenter[2];
+            const bool outside = !(fma_(qz, qz, fma_(qy, qy, qx * qx)) <= a.crmax2);
+            for (uint32_t g0 = 0; g0 < a.n_clusters; g0 += 64u) {
+                bool reach = false;
+                if (g0 + lane < a.n_clusters) {
+                    const float4 mid = bounds[2u * (g0 + lane)], half = bounds[2u * (g0 + lane) + 1u];
+                    const float tcx = fma_(mid.x, ix, ax), tcy = fma_(mid.y, iy, ay), tcz = fma_(mid.z, iz, az);
+                    const float tn = __builtin_fmaxf(__builtin_fmaxf(fma_(-half.x, jx, tcx), fma_(-half.y, jy, tcy)),
+                                                     __builtin_fmaxf(fma_(-half.z, jz, tcz), 0.0f));
+                    const float tf = __builtin_fminf(__builtin_fminf(fma_(half.x, jx, tcx), fma_(half.y, jy, tcy)),
+                                                     fma_(half.z, jz, tcz));
+                    reach = outside || !__builtin_signbit(tf - tn);
+                    ++n_tests;
+                }
+                unsigned long long todo = __ballot(reach);
+                while (todo != 0ull) {  // four clusters per pass, one member per lane
+                    int c[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        c[q] = todo != 0ull ? __builtin_ctzll(todo) : -1;
+                        todo &= todo - 1ull;   // (0 stays 0)
+                    }
+                    const uint32_t q = lane >> 4;
+                    const int mine = q == 0u ? c[0] : (q == 1u ? c[1] : (q == 2u ? c[2] : c[3]));
+                    if (mine >= 0) {
+                        examine_keyed(slots, idx_map,
+                                      a.n_large_slots + (g0 + static_cast<uint32_t>(mine)) * kClusterStride + (lane & 15u),
+                                      ox, oy, oz, dx, dy, dz, key);
+                        ++n_tests;
+                    }
+                }
+            }
+            // wave minimum of the 64-bit key: distances first, then (index, slot) among the nearest
+            const uint32_t hi = static_cast<uint32_t>(key >> 32);
+            const uint32_t hi_min = wave_min_u32(hi);
+            const uint32_t lo_min = wave_min_u32(hi == hi_min ? static_cast<uint32_t>(key) : 0xFFFFFFFFu);
+            if (lane == static_cast<uint32_t>(src) && hi_min != 0xFFFFFFFFu) {
+                best[r] = __uint_as_float(hi_min);
+                best_i[r] = static_cast<int>(lo_min & 0xFFFFu);
+                best_o[r] = lo_min >> 16;
+            }
+        }
+    }
+}
+
 DI uint32_t lane_rank(unsigned long long mask) {  // number of set bits of mask below this lane
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
@@ -915,14 +1027,18 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
     bool exhausted = false;                  // the global queue has been drained
     bool tail_done = false;                  // this wave has been through the workgroup's tail merge
     // a wave parks at most kDonateMax paths, so that all donors fit the pool
-    const uint32_t donate_max = waves_in_group > 1u ? (kTailPool / (waves_in_group - 1u) < kSparseMax
-                                                            ? kTailPool / (waves_in_group - 1u) : kSparseMax) : 0u;
+    const uint32_t donate_max = waves_in_group > 1u ? (kTailPool / (waves_in_group - 1u) < kDonateMax
+                                                            ? kTailPool / (waves_in_group - 1u) : kDonateMax) : 0u;
     uint32_t n_paths = 0, n_segments = 0, n_tests = 0;
     [[maybe_unused]] uint32_t dbg_slow_trips = 0, dbg_cands = 0, dbg_iters = 0, dbg_sparse = 0;
     [[maybe_unused]] unsigned long long dbg_t_refill = 0, dbg_t_trace = 0, dbg_t_slow = 0, dbg_t_shade = 0;
     [[maybe_unused]] const unsigned long long dbg_c0 = DBG_STAMP();
 #ifdef RTIOW_DEBUG_COUNTERS
     const unsigned long long dbg_w0 = wall_clock64();
+    if (lane == 0u) atomicMax(&a.counters->not_t0, ~dbg_w0);
+    bool dbg_dry_seen = false;
+    unsigned long long dbg_dry_at = 0ull, dbg_sp_ticks = 0ull;
+    uint32_t dbg_tail_iters = 0u, dbg_sp_iters = 0u, dbg_sp_paths = 0u;
 #endif
 
     for (;;) {
@@ -974,6 +1090,15 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
                         }
                         if (!fetched) {
                             exhausted = true;
+#ifdef RTIOW_DEBUG_COUNTERS
+                            if (!dbg_dry_seen && lane == 0u) {
+                                const unsigned long long t0w = ~__hip_atomic_load(&a.counters->not_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const unsigned long long b = (wall_clock64() - t0w) / 12500ull;
+                                atomicAdd(&a.counters->hist_dry[b > 31ull ? 31ull : b], 1u);
+                            }
+                            if (!dbg_dry_seen) dbg_dry_at = wall_clock64();
+                            dbg_dry_seen = true;
+#endif
                             break;
                         }
                     }
@@ -1099,11 +1224,25 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
         uint32_t live_paths = 0u;
 #pragma unroll
         for (int r = 0; r < kSlots; ++r) live_paths += static_cast<uint32_t>(__popcll(__ballot(sl[r].active)));
-        if (live_paths <= kSparseMax) {
-            trace_sparse<kSlots>(lds_spheres, ACCEL ? lds_cidx : nullptr, g.n_pad, a.n, sl, best, best_i, best_o);
+#ifdef RTIOW_DEBUG_COUNTERS
+        if (dbg_dry_seen) ++dbg_tail_iters;
+        const unsigned long long dbg_tr0 = wall_clock64();
+#endif
+        if (ACCEL && live_paths <= kSparseMaxAccel) {
+            trace_sparse_clustered<kSlots>(lds_spheres, lds_cidx, lds_cbounds, a, sl, best, best_i, best_o, n_tests);
+            DBG_ADD(dbg_sparse, lane == 0u ? 1u : 0u);
+#ifdef RTIOW_DEBUG_COUNTERS
+            if (dbg_dry_seen) {
+                dbg_sp_ticks += wall_clock64() - dbg_tr0;
+                ++dbg_sp_iters;
+                dbg_sp_paths += live_paths;
+            }
+#endif
+        } else if (!ACCEL && live_paths <= kSparseMax) {
+            trace_sparse<kSlots>(lds_spheres, nullptr, g.n_pad, a.n, sl, best, best_i, best_o);
 #pragma unroll
             for (int r = 0; r < kSlots; ++r)
-                if (sl[r].active) n_tests += ACCEL ? g.n_pad : a.n;
+                if (sl[r].active) n_tests += a.n;
             DBG_ADD(dbg_sparse, lane == 0u ? 1u : 0u);
         } else if (ACCEL) {
             trace_clustered<kSlots>(lds_spheres, lds_cidx, lds_cbounds, a, lds_items, lds_results, sl, best, best_i, best_o, n_tests,
@@ -1202,6 +1341,18 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
         atomicAdd(&a.counters->debug[4], dbg_t_trace);
         atomicAdd(&a.counters->debug[5], dbg_t_slow);
         atomicAdd(&a.counters->debug[6], dbg_t_shade);
+        {
+            const unsigned long long t0w = ~__hip_atomic_load(&a.counters->not_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long b = (wall_clock64() - t0w) / 12500ull;
+            atomicAdd(&a.counters->hist_end[b > 31ull ? 31ull : b], 1u);
+            if (dbg_dry_seen) {
+                atomicAdd(&a.counters->tail_iters, static_cast<unsigned long long>(dbg_tail_iters));
+                atomicAdd(&a.counters->tail_ticks, wall_clock64() - dbg_dry_at);
+                atomicAdd(&a.counters->tail_sparse_iters, static_cast<unsigned long long>(dbg_sp_iters));
+                atomicAdd(&a.counters->tail_sparse_ticks, dbg_sp_ticks);
+                atomicAdd(&a.counters->tail_sparse_paths, static_cast<unsigned long long>(dbg_sp_paths));
+            }
+        }
         if (blockIdx.x == 0 && threadIdx.x == 0) {  // clock = shader cycles per 100 MHz tick
             const unsigned long long dc = DBG_STAMP() - dbg_c0, dw = wall_clock64() - dbg_w0;
             a.counters->debug[7] = dw ? dc * 100ull / dw : 0ull;  // MHz
@@ -1278,7 +1429,7 @@ hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, in
     g.n_pad = accel ? a.n_cslots : (a.n + kBlockSph - 1u) / kBlockSph * kBlockSph;
     (void)max_take;  // scheduling is per sample now; the hint is accepted and ignored
     g.total_pix = a.local_rows * a.width;
-    g.pool_pix = RTIOW_POOL_SAMPLES / a.spp;  // a few pixels per pool; one pixel when spp is large
+    g.pool_pix = (accel ? RTIOW_POOL_SAMPLES_ACCEL : RTIOW_POOL_SAMPLES) / a.spp;  // a few pixels per pool; one pixel when spp is large
     g.pool_pix = g.pool_pix < 1u ? 1u : (g.pool_pix > 256u ? 256u : g.pool_pix);
     // LDS per workgroup: the sphere list (16 B per slot; clustered: + 4 B per slot of indices and
     // 32 B per cluster box); while the scene is small, the shading records too (32 B each);
