@@ -108,8 +108,8 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames rendered concurrently on separate contexts/streams, as the reference keeps one "
                          "compute fence per swapchain image (RTCHAP06/main.cpp:94-98,313-316); 0 = auto: 1 on one "
-                         "GPU (clean per-kernel roofline), 2 on several (a frame's tail of long paths and its "
-                         "gather overlap the next frame)")
+                         "GPU (clean per-kernel roofline), 3 on several (a tile's tail of long paths -- a third of its "
+                         "time at 1/8 frame -- and its gather overlap the next frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extras (two frames in flight, the other kernel): profiling runs")
@@ -147,7 +147,7 @@ def main():
 
     scene, grid_half, w, h, spp, depth = WORKLOADS[args.workload]
     sph, mat, cam = build_scene(V, scene, grid_half, w, h)
-    F = args.frames_in_flight if args.frames_in_flight > 0 else (1 if world == 1 else 2)
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (1 if world == 1 else 3)
     prm = V.make_params(w, h, spp=spp, max_depth=depth, seed=1, chunk_spp=args.chunk_spp,
                         quantiser=V.RT_QUANT_BOOK, row_block=args.row_block if world > 1 else 0,
                         tile_rank=rank if world > 1 else 0, tile_count=world if world > 1 else 0,
@@ -213,13 +213,14 @@ def main():
         value = nominal / (elapsed / args.steps) / 1e6
         n = len(sph)
         eff_kernel = ctx.last_kernel()   # what RtParams.kernel 0 resolved to
-        # dominant kernel: the path-trace kernel of rank 0's tile (per launch).  Algorithmic flops per
-        # every segment against the whole hittable list, segments * (16 N + 60) -- the work
-        # the north-star algorithm defines, whichever kernel ran.  The clustered kernel reaches the same
-        # hits with fewer tests; what it executed is reported beside it.
-        flops = st.segments * (n * FLOPS_PER_TEST + FLOPS_PER_SEGMENT_SHADE)
+        # dominant kernel: the path-trace kernel of rank 0's tile (per launch).  Flops per segment =
+        # 16 per ray-sphere / ray-box test the kernel's algorithm performs + 60 of shading (SURVEY 8d with
+        # a = 1).  The flat list tests all N spheres per segment; the clustered list's count depends on
+        # the rays and is taken from the kernel's own counter.  `flat_list_equivalent` rates the same
+        # frame as if every segment had met the whole list (SURVEY 8d's literal 16 N + 60).
+        flops = st.sphere_tests * FLOPS_PER_TEST + st.segments * FLOPS_PER_SEGMENT_SHADE
         achieved = flops / (kernel_ms * 1e-3) / 1e12
-        executed = (st.sphere_tests * FLOPS_PER_TEST + st.segments * FLOPS_PER_SEGMENT_SHADE) / (kernel_ms * 1e-3) / 1e12
+        flat_equiv = st.segments * (n * FLOPS_PER_TEST + FLOPS_PER_SEGMENT_SHADE) / (kernel_ms * 1e-3) / 1e12
         fb_bytes = st.bytes_written
         traffic = None
         if world == 1:  # PMC traffic of this workload + kernel, newest profile first
@@ -246,13 +247,15 @@ def main():
             "roofline": {
                 "bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": traffic,
-                "note": "fp32 vector-ALU bound (no dense contraction: MFMA unused by design); algorithmic "
-                        f"flops (SURVEY 8d) = segments*(N*{FLOPS_PER_TEST} + {FLOPS_PER_SEGMENT_SHADE}): every segment "
-                        "against the whole hittable list; kernel time = HIP events on the launch stream over the "
-                        "timed steps.  `executed` counts the tests the kernel really made (the clustered list "
-                        "skips most of them, so its algorithmic rate is not a VALU utilisation)",
-                "executed": {"achieved": executed, "frac": executed / FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "tests_per_segment": st.sphere_tests / max(1, st.segments)},
+                "note": "fp32 vector-ALU bound (no dense contraction: MFMA unused by design); flops = "
+                        f"tests*{FLOPS_PER_TEST} + segments*{FLOPS_PER_SEGMENT_SHADE}, tests from the kernel's counter "
+                        "(flat list: segments*N; clustered list: large spheres + cluster boxes + members of the boxes "
+                        "a ray reaches); kernel time = HIP events on the launch stream over the timed steps",
+                "tests_per_segment": st.sphere_tests / max(1, st.segments),
+                "flat_list_equivalent": {"achieved": flat_equiv, "frac": flat_equiv / FP32_VALU_PEAK_TFLOPS,
+                                         "unit": "TFLOP/s", "note": "segments*(16 N + 60): the flat list's work for "
+                                         "the same frame over this kernel's time; above 1 means the acceleration "
+                                         "structure beats any possible flat-list kernel"},
                 "hbm_write": {"achieved": fb_bytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": fb_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "bytes_per_launch": fb_bytes},
@@ -284,8 +287,10 @@ def main():
                 ctx.render_device(cam, oprm, locals_[0].data_ptr(), w * 4, streams[0].cuda_stream)
                 oms.append(ctx.stats().kernel_ms)
             ost = ctx.stats()
+            oflops = ost.sphere_tests * FLOPS_PER_TEST + ost.segments * FLOPS_PER_SEGMENT_SHADE
             out["config"]["other_kernel"] = {"kernel": KERNEL_NAMES[other], "kernel_ms": min(oms),
-                                             "tests_per_segment": ost.sphere_tests / max(1, ost.segments)}
+                                             "tests_per_segment": ost.sphere_tests / max(1, ost.segments),
+                                             "roofline_frac": oflops / (min(oms) * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(V, sph, mat, cam, w, h, spp, depth, args.chunk_spp, args.cpu_seconds)
         print(json.dumps(out), flush=True)

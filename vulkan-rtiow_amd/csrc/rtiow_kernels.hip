@@ -445,18 +445,18 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 // the oracle's sequential scan computes.
 
 // Samples a wave takes from its queue at a time.  A fetch costs two dependent atomics on a head that
-// thousands of waves share (microseconds, during which the wave's idle lanes wait), so pools must last a
-// few iterations; too large and the end of the frame balances badly.  Measured (tools/ab_bench.py, cover
-// frame): flat list 100 -> 36.3 ms, 200 -> 31.3, 300..768 -> 29.8-30.5, 2048 -> 32.6; clustered list
-// (2.6x fewer cycles per sample) 128 -> 35.0, 256 -> 19.0, 384 -> 14.2, 768 -> 12.0, 1536 -> 11.4,
-// 3072 -> 11.9.  Asking for the next pool ahead of time (one atomic in flight per wave) reaches the same
-// 11.5 ms at any pool size but costs the flat list 2 ms in registers: not used.
-#ifndef RTIOW_POOL_SAMPLES
-#define RTIOW_POOL_SAMPLES 384u
+// thousands of waves share (microseconds, during which the wave's idle lanes wait), so a pool must last
+// a few iterations; too large and the end of the frame balances badly.  Measured (tools/ab_bench.py, cover
+// frame): flat list (486 tests per segment) 100 -> 36.3 ms, 200 -> 31.3, 300..768 -> 29.8-30.5, 2048 ->
+// 32.6; clustered list (58 tests per segment, 2.6x fewer cycles per sample) 128 -> 35.0, 256 -> 19.0,
+// 384 -> 14.2, 768 -> 12.0, 1536 -> 11.4, 3072 -> 11.9.  Both optima sit near kPoolWork / (tests per
+// segment the kernel will make): launch_path sizes the pool that way.  Asking for the next pool ahead of
+// time (one atomic in flight per wave) reaches the same 11.5 ms at any pool size but costs the flat
+// list 2 ms in registers: not used.
+#ifndef RTIOW_POOL_WORK
+#define RTIOW_POOL_WORK 150000u
 #endif
-#ifndef RTIOW_POOL_SAMPLES_ACCEL
-#define RTIOW_POOL_SAMPLES_ACCEL 1536u
-#endif
+constexpr uint32_t kPoolWork = RTIOW_POOL_WORK;
 constexpr int kSlots = 2;           // path slots per lane
 constexpr uint32_t kBlockSph = 32;  // spheres per candidate word
 #ifndef RTIOW_SPARSE_MAX
@@ -1429,7 +1429,12 @@ hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, in
     g.n_pad = accel ? a.n_cslots : (a.n + kBlockSph - 1u) / kBlockSph * kBlockSph;
     (void)max_take;  // scheduling is per sample now; the hint is accepted and ignored
     g.total_pix = a.local_rows * a.width;
-    g.pool_pix = (accel ? RTIOW_POOL_SAMPLES_ACCEL : RTIOW_POOL_SAMPLES) / a.spp;  // a few pixels per pool; one pixel when spp is large
+    // tests a segment costs, roughly: the whole list, or large spheres + boxes (14 of 11 instructions)
+    // + 1.4 clusters of 16 at half the lane efficiency
+    const uint32_t seg_cost = accel ? a.n_large + a.n_clusters * 14u / 11u + 44u : a.n;
+    uint32_t pool_samples = kPoolWork / (seg_cost < 1u ? 1u : seg_cost);
+    pool_samples = pool_samples < 256u ? 256u : (pool_samples > 4096u ? 4096u : pool_samples);
+    g.pool_pix = pool_samples / a.spp;  // a few pixels per pool; one pixel when spp is large
     g.pool_pix = g.pool_pix < 1u ? 1u : (g.pool_pix > 256u ? 256u : g.pool_pix);
     // LDS per workgroup: the sphere list (16 B per slot; clustered: + 4 B per slot of indices and
     // 32 B per cluster box); while the scene is small, the shading records too (32 B each);

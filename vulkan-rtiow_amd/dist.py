@@ -32,6 +32,25 @@ def max_tile_rows(height: int, row_block: int, world: int) -> int:
     return max(len(tile_rows(height, row_block, r, world)) for r in range(max(1, world)))
 
 
+_scatter_rows_cache: dict = {}
+
+
+def _scatter_rows(height: int, row_block: int, world: int, device) -> torch.Tensor:
+    """Destination row of every (rank, padded local row) of the gathered buffer; padding rows go to the
+    scratch row `height`.  Built once per partition and device (no per-frame host-to-device copies)."""
+    key = (height, row_block, world, str(device))
+    hit = _scatter_rows_cache.get(key)
+    if hit is None:
+        pad_rows = max_tile_rows(height, row_block, world)
+        dest = np.full((world, pad_rows), height, dtype=np.int64)
+        for r in range(world):
+            rows = tile_rows(height, row_block, r, world)
+            dest[r, : len(rows)] = rows
+        hit = torch.from_numpy(dest.reshape(-1)).to(device)
+        _scatter_rows_cache[key] = hit
+    return hit
+
+
 def gather_frame(local: torch.Tensor, height: int, row_block: int, rank: int, world: int,
                  dst: int = 0, group=None) -> Optional[torch.Tensor]:
     """Gathers every rank's packed rows ([rows_r, width] int32, RGBA8 packed) to `dst` and
@@ -50,12 +69,12 @@ def gather_frame(local: torch.Tensor, height: int, row_block: int, rank: int, wo
         send[: local.shape[0]] = local
     send = send.contiguous()
     if rank == dst:
-        parts = [torch.empty_like(send) for _ in range(world)]
-        dist.gather(send, gather_list=parts, dst=dst, group=group)
-        frame = torch.empty((height, width), dtype=local.dtype, device=local.device)
-        for r in range(world):
-            rows = torch.from_numpy(tile_rows(height, row_block, r, world)).to(local.device)
-            frame.index_copy_(0, rows, parts[r][: len(rows)])
-        return frame
+        # one receive buffer [world, pad_rows, width]; one scatter of its rows into the frame
+        # (plus a scratch row that swallows the padding)
+        recv = torch.empty((world, pad_rows, width), dtype=local.dtype, device=local.device)
+        dist.gather(send, gather_list=list(recv.unbind(0)), dst=dst, group=group)
+        frame = torch.empty((height + 1, width), dtype=local.dtype, device=local.device)
+        frame.index_copy_(0, _scatter_rows(height, row_block, world, local.device), recv.view(world * pad_rows, width))
+        return frame[:height]
     dist.gather(send, gather_list=None, dst=dst, group=group)
     return None
