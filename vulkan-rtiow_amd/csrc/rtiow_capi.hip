@@ -411,6 +411,10 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
                     c.tail_iters, c.tail_iters ? c.tail_ticks * 0.01 / c.tail_iters : 0.0, c.tail_sparse_iters,
                     c.tail_sparse_iters ? c.tail_sparse_ticks * 0.01 / c.tail_sparse_iters : 0.0,
                     c.tail_sparse_iters ? double(c.tail_sparse_paths) / c.tail_sparse_iters : 0.0);
+            if (c.tail_iters)
+                fprintf(stderr, "tail iteration, shader cycles: refill+merge %.0f trace %.0f shade %.0f\n",
+                        double(c.tail_cyc[0]) / c.tail_iters, double(c.tail_cyc[1]) / c.tail_iters,
+                        double(c.tail_cyc[2]) / c.tail_iters);
         }
     }
     *out = ctx->stats;

@@ -10,10 +10,17 @@
 namespace rtiow {
 
 // Device-side counters, one block per context (zeroed before every render).
+// Head of one per-XCD pixel queue, alone on its 128-byte line: atomics on one line are serialised by
+// its L2 channel (~90 per microsecond), eight heads on one line would share that budget.
+struct alignas(128) QueueHead {
+    unsigned int next;              // first virtual pixel not handed out yet
+    unsigned int pad[31];
+};
+
 struct Counters {
+    QueueHead xcd_head[8];          // persistent kernel: heads of the eight per-XCD pixel queues
     unsigned long long paths;
     unsigned long long segments;
-    unsigned int xcd_head[8];       // persistent kernel: heads of the eight per-XCD pixel queues
     unsigned long long tests;       // ray-sphere and ray-bound tests performed
     unsigned long long debug[8];    // diagnostic builds (-DRTIOW_DEBUG_COUNTERS) only
     unsigned long long not_t0;      // diagnostic builds: ~(earliest wave start), 100 MHz ticks
@@ -21,6 +28,7 @@ struct Counters {
     unsigned int hist_end[32];      // diagnostic builds: waves by the time they finished
     unsigned long long tail_iters, tail_ticks;  // diagnostic builds: iterations / 100 MHz ticks of all waves after running dry
     unsigned long long tail_sparse_iters, tail_sparse_ticks, tail_sparse_paths;  // the sparse ones among them
+    unsigned long long tail_cyc[3];  // diagnostic builds: shader cycles of the tail iterations in refill / trace / shade
 };
 
 // Device-side shading record of one sphere (32 B), built by rtSetScene from RtSphere + RtMaterial.

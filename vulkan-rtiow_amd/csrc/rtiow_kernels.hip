@@ -444,17 +444,18 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 // sphere's first root in (t_min, inf), ties to the lowest index — exactly what
 // the oracle's sequential scan computes.
 
-// Samples a wave takes from its queue at a time.  A fetch costs two dependent atomics on a head that
-// thousands of waves share (microseconds, during which the wave's idle lanes wait), so a pool must last
-// a few iterations; too large and the end of the frame balances badly.  Measured (tools/ab_bench.py, cover
-// frame): flat list (486 tests per segment) 100 -> 36.3 ms, 200 -> 31.3, 300..768 -> 29.8-30.5, 2048 ->
-// 32.6; clustered list (58 tests per segment, 2.6x fewer cycles per sample) 128 -> 35.0, 256 -> 19.0,
-// 384 -> 14.2, 768 -> 12.0, 1536 -> 11.4, 3072 -> 11.9.  Both optima sit near kPoolWork / (tests per
-// segment the kernel will make): launch_path sizes the pool that way.  Asking for the next pool ahead of
-// time (one atomic in flight per wave) reaches the same 11.5 ms at any pool size but costs the flat
-// list 2 ms in registers: not used.
+// Samples a wave takes from its queue at a time.  A fetch costs two dependent atomics on the queue's
+// head, microseconds when many waves share it, during which the wave's idle lanes wait: a pool must
+// last a few iterations; too large and the end of the frame balances badly.  The eight heads sit on
+// separate 128-byte lines (rtiow_device.h).  While they shared one line -- one L2 channel serialising
+// every fetch of the chip -- small pools were ruinous (cover frame, clustered list: 128 samples -> 35.0
+// ms, 384 -> 14.2, 1536 -> 11.4; flat list: 100 -> 36.3, 384 -> 29.8) and the sweep over all eight
+// drying queues at the end of a frame stalled every wave for ~180 us.  With separate lines
+// (tools/ab_bench.py, clustered list, full frame / one eighth of it): 1700 samples 10.97 / 3.00 ms,
+// 850 -> 10.48 / 2.29, 450 -> 10.46 / 2.05, 256 -> 10.5 / 1.95; flat list 29.5 / 5.4 from 256 to 450.
+// launch_path takes kPoolWork / (tests a segment costs) samples, at least 256.
 #ifndef RTIOW_POOL_WORK
-#define RTIOW_POOL_WORK 150000u
+#define RTIOW_POOL_WORK 40000u
 #endif
 constexpr uint32_t kPoolWork = RTIOW_POOL_WORK;
 constexpr int kSlots = 2;           // path slots per lane
@@ -1039,6 +1040,7 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
     bool dbg_dry_seen = false;
     unsigned long long dbg_dry_at = 0ull, dbg_sp_ticks = 0ull;
     uint32_t dbg_tail_iters = 0u, dbg_sp_iters = 0u, dbg_sp_paths = 0u;
+    unsigned long long dbg_tail_cyc[3] = {0ull, 0ull, 0ull};
 #endif
 
     for (;;) {
@@ -1069,14 +1071,14 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
                             const uint32_t vsize = ((n_chunks + 7u - xq) / 8u) * kChunkPix;  // virtual pixels of queue xq
                             uint32_t head_now = 0u;
                             if (lane == 0u)
-                                head_now = __hip_atomic_load(&a.counters->xcd_head[xq], __ATOMIC_RELAXED,
+                                head_now = __hip_atomic_load(&a.counters->xcd_head[xq].next, __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_AGENT);
                             head_now = __builtin_amdgcn_readfirstlane(head_now);
                             if (head_now < vsize) {
                                 uint32_t k = (vsize - head_now) / (g.total_waves / 4u + 1u);  // ~waves per XCD x 2
                                 k = k < 1u ? 1u : (k > g.pool_pix ? g.pool_pix : k);
                                 uint32_t got = 0u;
-                                if (lane == 0u) got = atomicAdd(&a.counters->xcd_head[xq], k);
+                                if (lane == 0u) got = atomicAdd(&a.counters->xcd_head[xq].next, k);
                                 got = __builtin_amdgcn_readfirstlane(got);
                                 if (got < vsize) {
                                     pool_next = got;
@@ -1315,6 +1317,13 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
         DBG_ADD(dbg_t_refill, t1 - t0);
         DBG_ADD(dbg_t_trace, t2 - t1);
         DBG_ADD(dbg_t_shade, DBG_STAMP() - t2);
+#ifdef RTIOW_DEBUG_COUNTERS
+        if (dbg_dry_seen) {
+            dbg_tail_cyc[0] += t1 - t0;
+            dbg_tail_cyc[1] += t2 - t1;
+            dbg_tail_cyc[2] += DBG_STAMP() - t2;
+        }
+#endif
     }
 
     // one counter update per wave
@@ -1351,6 +1360,7 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
                 atomicAdd(&a.counters->tail_sparse_iters, static_cast<unsigned long long>(dbg_sp_iters));
                 atomicAdd(&a.counters->tail_sparse_ticks, dbg_sp_ticks);
                 atomicAdd(&a.counters->tail_sparse_paths, static_cast<unsigned long long>(dbg_sp_paths));
+                for (int k = 0; k < 3; ++k) atomicAdd(&a.counters->tail_cyc[k], dbg_tail_cyc[k]);
             }
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) {  // clock = shader cycles per 100 MHz tick
