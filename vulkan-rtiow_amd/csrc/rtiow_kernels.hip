@@ -454,6 +454,10 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 // (tools/ab_bench.py, clustered list, full frame / one eighth of it): 1700 samples 10.97 / 3.00 ms,
 // 850 -> 10.48 / 2.29, 450 -> 10.46 / 2.05, 256 -> 10.5 / 1.95; flat list 29.5 / 5.4 from 256 to 450.
 // launch_path takes kPoolWork / (tests a segment costs) samples, at least 256.
+// Tried on top of this and dropped (each cost the full frame 2-7 %): asking for the next pool ahead of
+// time (one atomic in flight per wave); lanes 0-7 looking at all eight heads in one round trip, on every
+// fetch or only once the wave's own queue is dry (the queue-by-queue sweep at the very end of a frame
+// costs a wave ~65 us, but eight loads per fetch on contended lines cost more).
 #ifndef RTIOW_POOL_WORK
 #define RTIOW_POOL_WORK 40000u
 #endif
