@@ -256,8 +256,11 @@ DI bool scatter(f3 ctr, const ShadeRec& m, float s, Path& p) {
     const bool front = dn < 0.0f;
     const f3 n = front ? outward : mk(-outward.x, -outward.y, -outward.z);
     f3 dir;
+    // lambertian and fuzzy metal both start with one random unit vector: drawn once for the lanes of
+    // either kind (in a wave all material branches are taken anyway, so this halves that code)
+    f3 rv = mk(0.0f, 0.0f, 0.0f);
+    if (m.kind == RT_MAT_LAMBERTIAN || (m.kind == RT_MAT_METAL && m.param > 0.0f)) rv = random_unit_vector(p.rng);
     if (m.kind == RT_MAT_LAMBERTIAN) {
-        const f3 rv = random_unit_vector(p.rng);
         dir = mk(n.x + rv.x, n.y + rv.y, n.z + rv.z);
         if (__builtin_fabsf(dir.x) < 1e-8f && __builtin_fabsf(dir.y) < 1e-8f &&
             __builtin_fabsf(dir.z) < 1e-8f)
@@ -267,10 +270,8 @@ DI bool scatter(f3 ctr, const ShadeRec& m, float s, Path& p) {
         const float k2 = 2.0f * dot3(p.du, n);
         const f3 refl = mk(fma_(-k2, n.x, p.du.x), fma_(-k2, n.y, p.du.y), fma_(-k2, n.z, p.du.z));
         dir = refl;
-        if (m.param > 0.0f) {  // fuzz
-            const f3 rs = random_unit_vector(p.rng);
-            dir = mk(fma_(m.param, rs.x, refl.x), fma_(m.param, rs.y, refl.y), fma_(m.param, rs.z, refl.z));
-        }
+        if (m.param > 0.0f)  // fuzz
+            dir = mk(fma_(m.param, rv.x, refl.x), fma_(m.param, rv.y, refl.y), fma_(m.param, rv.z, refl.z));
         if (!(dot3(dir, n) > 0.0f)) return false;
         p.att = mk(p.att.x * m.albedo[0], p.att.y * m.albedo[1], p.att.z * m.albedo[2]);
     } else {
