@@ -75,11 +75,12 @@ def test_default_kernel_choice(gpu_ctx):
     assert gpu_ctx.last_kernel() == V.KERNEL_PERSISTENT
 
 
-@pytest.mark.parametrize("n", [40, 330])
+@pytest.mark.parametrize("n", [40, 330, 1400])
 def test_rays_from_outside_the_box_range(gpu_ctx, oracle, n):
     """A tight knot of spheres on a huge ground, wide camera: most bounces start on the ground far
     outside the range the cluster boxes are inflated for (2 scene diagonals) and must walk every
-    cluster; with 330 spheres a wave's pooled work list overflows and each lane walks its own."""
+    cluster; with 330 spheres a wave's pooled work list overflows and each lane walks its own; with 1400
+    the scene has super-clusters and it is their list that overflows."""
     rng = np.random.default_rng(77 + n)
     sph = np.zeros(n + 1, V.SPHERE_DTYPE)
     mat = np.zeros(n + 1, V.MATERIAL_DTYPE)

@@ -24,7 +24,7 @@ struct RtContext {
     float4* d_cslots = nullptr;   // clustered list (rtiow_clusters.cpp)
     uint32_t* d_cidx = nullptr;
     float4* d_cbounds = nullptr;
-    uint32_t n_clusters = 0, n_large = 0, n_large_slots = 0, n_cslots = 0;
+    uint32_t n_clusters = 0, n_super = 0, n_large = 0, n_large_slots = 0, n_cslots = 0;
     float cluster_center[3] = {0, 0, 0};
     float cluster_diag = 0, cluster_rmax2 = 0;
     uint32_t last_kernel = 0;     // variant the last PATH render launched
@@ -207,6 +207,7 @@ int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materi
     RT_HIP(ctx, hipMemcpy(ctx->d_cidx, cs.idx.data(), sizeof(uint32_t) * cs.idx.size(), hipMemcpyHostToDevice));
     RT_HIP(ctx, hipMemcpy(ctx->d_cbounds, cs.bounds.data(), sizeof(float4) * cs.bounds.size(), hipMemcpyHostToDevice));
     ctx->n_clusters = cs.n_clusters;
+    ctx->n_super = cs.n_super;
     ctx->n_large = cs.n_large;
     ctx->n_large_slots = cs.n_large_slots;
     ctx->n_cslots = static_cast<uint32_t>(cs.slots.size());
@@ -271,6 +272,7 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         a.cidx = ctx->d_cidx;
         a.cbounds = ctx->d_cbounds;
         a.n_clusters = ctx->n_clusters;
+        a.n_super = ctx->n_super;
         a.n_large = ctx->n_large;
         a.n_large_slots = ctx->n_large_slots;
         a.n_cslots = ctx->n_cslots;

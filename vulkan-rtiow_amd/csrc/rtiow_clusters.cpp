@@ -145,15 +145,52 @@ void build_clusters(const RtSphere* sph, uint32_t n, ClusterScene& out) {
         out.bounds.push_back(mid);
         out.bounds.push_back(half);
     }
-    // pad the cluster count to a multiple of 4 (the unroll of the box loop) with empty clusters whose
-    // box is a point far outside any scene (reaching it by accident only costs 16 never-hit tests)
-    while ((out.bounds.size() / 2u) % 4u) {
+    // pad the cluster count to a multiple of kSuperSize (and of the box loop's unroll of 4) with empty
+    // clusters whose box is a point far outside any scene (reaching it by accident only costs 16
+    // never-hit tests)
+    const size_t n_real_clusters = out.bounds.size() / 2u;
+    while ((out.bounds.size() / 2u) % kSuperSize) {
         out.bounds.push_back(ClusterF4{3e18f, 3e18f, 3e18f, 0.0f});
         out.bounds.push_back(ClusterF4{0.0f, 0.0f, 0.0f, 0.0f});
         out.slots.resize(out.slots.size() + kClusterStride, never);
         out.idx.resize(out.idx.size() + kClusterStride, 0xFFFFFFFFu);
     }
     out.n_clusters = static_cast<uint32_t>(out.bounds.size() / 2u);
+    // Large scenes get a level above: super-clusters of kSuperSize consecutive clusters (neighbours in
+    // the split tree), boxed by the union of their clusters' boxes.  The kernel then tests the super
+    // boxes in lock-step and the cluster boxes only for the (ray, super-cluster) pairs that pass.
+    out.n_super = 0;
+    if (out.n_clusters > kSuperFrom) {
+        out.n_super = out.n_clusters / kSuperSize;
+        for (uint32_t sc = 0; sc < out.n_super; ++sc) {
+            double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+            bool any = false;
+            for (uint32_t j = 0; j < kSuperSize; ++j) {
+                const size_t c = size_t(sc) * kSuperSize + j;
+                if (c >= n_real_clusters) continue;  // padding holds nothing
+                const ClusterF4 &mid = out.bounds[2u * c], &half = out.bounds[2u * c + 1u];
+                const double m[3] = {mid.x, mid.y, mid.z}, h[3] = {half.x, half.y, half.z};
+                for (int k = 0; k < 3; ++k) {
+                    blo[k] = std::min(blo[k], m[k] - h[k]);
+                    bhi[k] = std::max(bhi[k], m[k] + h[k]);
+                }
+                any = true;
+            }
+            ClusterF4 mid{3e18f, 3e18f, 3e18f, 0.0f}, half{0.0f, 0.0f, 0.0f, 0.0f};
+            if (any) {
+                float* mp[3] = {&mid.x, &mid.y, &mid.z};
+                float* hp[3] = {&half.x, &half.y, &half.z};
+                for (int k = 0; k < 3; ++k) {
+                    const float m = static_cast<float>(0.5 * (blo[k] + bhi[k]));
+                    *mp[k] = m;
+                    // the child boxes already carry the slab test's margin; keep the union exact, rounded outwards
+                    *hp[k] = round_up(std::max(bhi[k] - double(m), double(m) - blo[k]));
+                }
+            }
+            out.bounds.push_back(mid);
+            out.bounds.push_back(half);
+        }
+    }
 }
 
 }  // namespace rtiow

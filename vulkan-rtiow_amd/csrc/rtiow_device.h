@@ -45,6 +45,9 @@ struct ShadeRec {
 // the kernel, a stride of 16 slots (256 B = one LDS bank row) makes the bank of a read depend on the
 // lane only: conflict-free.
 constexpr uint32_t kClusterSize = 16, kClusterStride = 16;
+// Super-clusters (large scenes only): kSuperSize consecutive clusters under one box, from kSuperFrom
+// clusters on.
+constexpr uint32_t kSuperSize = 8, kSuperFrom = 64;
 
 struct PathArgs {
     const float4* spheres;       // n x {cx,cy,cz,radius} as uploaded (RtSphere)
@@ -54,7 +57,8 @@ struct PathArgs {
                                  // n_large_slots hold the large spheres, then kClusterStride per cluster
     const uint32_t* cidx;        // clustered: original index of every slot (0xFFFFFFFF = padding)
     const float4* cbounds;       // clustered: n_clusters x {box centre, box half extent}
-    uint32_t n_clusters;         // multiple of 4
+    uint32_t n_clusters;         // multiple of kSuperSize
+    uint32_t n_super;            // super-clusters (0: none); their boxes follow the clusters' in cbounds
     uint32_t n_large;            // large spheres (tested exactly by every ray)
     uint32_t n_large_slots;      // their slots: n_large padded to a multiple of kClusterSize
     uint32_t n_cslots;           // n_large_slots + n_clusters * kClusterStride
@@ -88,8 +92,8 @@ struct ClusterF4 {
 struct ClusterScene {  // host-side result of build_clusters
     std::vector<ClusterF4> slots;
     std::vector<uint32_t> idx;
-    std::vector<ClusterF4> bounds;  // two per cluster: centre, half extent
-    uint32_t n_clusters = 0;
+    std::vector<ClusterF4> bounds;  // two per cluster: centre, half extent; then two per super-cluster
+    uint32_t n_clusters = 0, n_super = 0;
     uint32_t n_large = 0, n_large_slots = 0;
     float center[3] = {0, 0, 0};  // of the clustered spheres
     float diag = 0;               // their extent

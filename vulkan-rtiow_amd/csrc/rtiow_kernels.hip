@@ -709,17 +709,89 @@ DI float slab_rcp(float d) {  // reciprocal of a direction component kept away f
     return __builtin_amdgcn_rcpf(c);
 }
 
-// Per-wave LDS of the clustered trace: the work list of phase 2 and the per-ray results.
-constexpr uint32_t kItemCap = 512;                          // (ray, cluster) items per group of 32 clusters
-constexpr uint32_t kWaveItemBytes = kItemCap * 2u + 128u * 8u;  // u16 items + one u64 key per path slot
+// Per-wave LDS of the clustered trace: the per-ray result keys, the (ray, cluster) work list of phase 2
+// and, for scenes with super-clusters, the (ray, super-cluster) list before it.
+constexpr uint32_t kItemCap = 512;  // items per list
+constexpr uint32_t kWaveResultBytes = 128u * 8u;  // one u64 key per path slot of the wave
+__host__ __device__ constexpr uint32_t wave_item_bytes(bool two_level) { return kWaveResultBytes + kItemCap * 2u * (two_level ? 2u : 1u); }
 
-// Phase 2 is where rays diverge: a ray reaches 3 clusters on average, the unluckiest of a wave's 64
-// four times that, so a loop "each lane walks its own clusters" runs at 25 % utilisation.  Instead the
-// wave pools its (ray, cluster) pairs in an LDS list — a prefix sum over the lanes' candidate counts
+// slab test of one box (centre, half extent) against a ray given by 1/d, -o/d: sign bit of the result
+// set = the ray leaves the box before it enters it (or before its origin)
+DI float slab_gap(const float4& mid, const float4& half, float ix, float iy, float iz, float ax, float ay, float az) {
+    const float tcx = fma_(mid.x, ix, ax);
+    const float tcy = fma_(mid.y, iy, ay);
+    const float tcz = fma_(mid.z, iz, az);
+    const float jx = __builtin_fabsf(ix), jy = __builtin_fabsf(iy), jz = __builtin_fabsf(iz);
+    // entry: latest of the three near planes and the origin; exit: earliest far plane
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(fma_(-half.x, jx, tcx), fma_(-half.y, jy, tcy)),
+                                     __builtin_fmaxf(fma_(-half.z, jz, tcz), 0.0f));
+    const float tf = __builtin_fminf(__builtin_fminf(fma_(half.x, jx, tcx), fma_(half.y, jy, tcy)),
+                                     fma_(half.z, jz, tcz));
+    return tf - tn;
+}
+
+// the ray of path slot (item bit 6) of lane (item bits 0-5), for every lane's own item
+template <int R>
+DI void fetch_item_ray(const Slot (&sl)[R], uint32_t item, float& ox, float& oy, float& oz, float& dx, float& dy,
+                       float& dz) {
+    static_assert(R == 2, "the work lists encode the path slot in one bit");
+    const int src = static_cast<int>(item & 63u);
+    const bool second = (item & 64u) != 0u;
+    const float ox0 = __shfl(sl[0].p.o.x, src), oy0 = __shfl(sl[0].p.o.y, src), oz0 = __shfl(sl[0].p.o.z, src);
+    const float dx0 = __shfl(sl[0].p.du.x, src), dy0 = __shfl(sl[0].p.du.y, src), dz0 = __shfl(sl[0].p.du.z, src);
+    const float ox1 = __shfl(sl[1].p.o.x, src), oy1 = __shfl(sl[1].p.o.y, src), oz1 = __shfl(sl[1].p.o.z, src);
+    const float dx1 = __shfl(sl[1].p.du.x, src), dy1 = __shfl(sl[1].p.du.y, src), dz1 = __shfl(sl[1].p.du.z, src);
+    ox = second ? ox1 : ox0;
+    oy = second ? oy1 : oy0;
+    oz = second ? oz1 : oz0;
+    dx = second ? dx1 : dx0;
+    dy = second ? dy1 : dy0;
+    dz = second ? dz1 : dz0;
+}
+
+// Phase 2 is where rays diverge: a ray reaches 1.4 clusters on average, the unluckiest of a wave's 64
+// several times that, so a loop "each lane walks its own clusters" runs at 25 % utilisation.  Instead
+// the wave pools its (ray, cluster) pairs in an LDS list — a prefix sum over the lanes' candidate counts
 // gives every lane the place of its items — and works through the list 64 items at a time, one
 // cluster per lane: the lane fetches the ray of the item (ds_bpermute), tests the 16 members and folds
 // the hit into the ray's result with an LDS atomic minimum on the packed key.  The minimum is
 // order-independent, so the result is the one the per-lane walk gives.
+// An item is lane | slot << 6 | (cluster - cluster_base) << 7.
+template <int R>
+DI void consume_items(const float4* slots, const uint32_t* idx_map, const PathArgs& a, const uint16_t* items,
+                      uint32_t total, uint32_t cluster_base, const Slot (&sl)[R], unsigned long long* results,
+                      uint32_t& n_tests, uint32_t& dbg_slow_trips) {
+    const uint32_t lane = threadIdx.x & 63u;
+    // a wave's LDS operations are performed in order: the list is complete for the reads below
+    for (uint32_t k0 = 0; k0 < total; k0 += 64u) {
+        DBG_ADD(dbg_slow_trips, lane == 0u ? 1u : 0u);
+        const bool valid = k0 + lane < total;
+        const uint32_t item = valid ? items[k0 + lane] : 0u;
+        float ox, oy, oz, dx, dy, dz;
+        fetch_item_ray(sl, item, ox, oy, oz, dx, dy, dz);
+        if (valid) {
+            unsigned long long k2 = ~0ull;
+            examine_cluster(slots, idx_map, a.n_large_slots + (cluster_base + (item >> 7)) * kClusterStride, lane, ox,
+                            oy, oz, dx, dy, dz, k2);
+            n_tests += kClusterSize;
+            if (k2 != ~0ull) atomicMin(&results[(item & 127u)], k2);  // ds_min_u64; slot * 64 + lane
+        }
+    }
+}
+
+// every cluster of cm (bit 31 = cluster g0), lane by lane: the fallback when a work list overflows
+DI void walk_clusters(const float4* slots, const uint32_t* idx_map, const PathArgs& a, uint32_t cm, uint32_t g0,
+                      const Path& p, unsigned long long& key, uint32_t& n_tests) {
+    const uint32_t lane = threadIdx.x & 63u;
+    while (cm) {
+        const uint32_t bit = static_cast<uint32_t>(__builtin_clz(cm));
+        cm &= ~(0x80000000u >> bit);
+        examine_cluster(slots, idx_map, a.n_large_slots + (g0 + bit) * kClusterStride, lane, p.o.x, p.o.y, p.o.z,
+                        p.du.x, p.du.y, p.du.z, key);
+        n_tests += kClusterSize;
+    }
+}
+
 template <int R>
 DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const float4* bounds, const PathArgs& a,
                         uint16_t* items, unsigned long long* results,
@@ -774,92 +846,149 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
             }
         }
     }
-    // ---- phases 1 and 2, 32 clusters at a time ----
-    for (uint32_t g0 = 0; g0 < a.n_clusters; g0 += 32u) {
-        uint32_t miss[R];
+    if (a.n_super == 0u) {
+        // ---- phases 1 and 2, 32 clusters at a time ----
+        for (uint32_t g0 = 0; g0 < a.n_clusters; g0 += 32u) {
+            uint32_t miss[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) miss[r] = 0u;
-        const uint32_t jn = a.n_clusters - g0 < 32u ? a.n_clusters - g0 : 32u;  // n_clusters is a multiple of 4
+            for (int r = 0; r < R; ++r) miss[r] = 0u;
+            const uint32_t jn = a.n_clusters - g0 < 32u ? a.n_clusters - g0 : 32u;  // n_clusters is a multiple of 8
 #pragma unroll 4
-        for (uint32_t j = 0; j < jn; ++j) {
-            const float4 mid = bounds[2u * (g0 + j)], half = bounds[2u * (g0 + j) + 1u];  // LDS broadcast
+            for (uint32_t j = 0; j < jn; ++j) {
+                const float4 mid = bounds[2u * (g0 + j)], half = bounds[2u * (g0 + j) + 1u];  // LDS broadcast
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float tcx = fma_(mid.x, ix[r], ax[r]);
-                const float tcy = fma_(mid.y, iy[r], ay[r]);
-                const float tcz = fma_(mid.z, iz[r], az[r]);
-                const float jx = __builtin_fabsf(ix[r]), jy = __builtin_fabsf(iy[r]), jz = __builtin_fabsf(iz[r]);
-                // entry: latest of the three near planes and the origin; exit: earliest far plane
-                const float tn = __builtin_fmaxf(__builtin_fmaxf(fma_(-half.x, jx, tcx), fma_(-half.y, jy, tcy)),
-                                                 __builtin_fmaxf(fma_(-half.z, jz, tcz), 0.0f));
-                const float tf = __builtin_fminf(__builtin_fminf(fma_(half.x, jx, tcx), fma_(half.y, jy, tcy)),
-                                                 fma_(half.z, jz, tcz));
-                miss[r] = __builtin_amdgcn_alignbit(miss[r], __float_as_uint(tf - tn), 31);  // exit before entry
+                for (int r = 0; r < R; ++r)
+                    miss[r] = __builtin_amdgcn_alignbit(
+                        miss[r], __float_as_uint(slab_gap(mid, half, ix[r], iy[r], iz[r], ax[r], ay[r], az[r])), 31);
             }
-        }
-        [[maybe_unused]] const unsigned long long ts0 = DBG_STAMP();
-        uint32_t cm[R];
-        uint32_t packed = 0u;  // candidate clusters of the lane, both slots
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            cm[r] = sl[r].active ? (outside[r] ? ~0u : ~miss[r]) << (32u - jn) : 0u;  // first cluster at bit 31
-            if (sl[r].active) n_tests += jn;
-            packed += static_cast<uint32_t>(__builtin_popcount(cm[r]));
-            DBG_ADD(dbg_cands, __builtin_popcount(cm[r]));
-        }
-        const uint32_t incl = wave_inclusive_sum(packed);  // over the lanes
-        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-        if (total == 0u) continue;
-        if (total > kItemCap) {
-            // (only when many rays start outside the boxes' range) each lane walks its own clusters
+            [[maybe_unused]] const unsigned long long ts0 = DBG_STAMP();
+            uint32_t cm[R];
+            uint32_t packed = 0u;  // candidate clusters of the lane, both slots
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const Path& p = sl[r].p;
-                uint32_t m = cm[r];
-                while (m) {
-                    const uint32_t bit = static_cast<uint32_t>(__builtin_clz(m));
-                    m &= ~(0x80000000u >> bit);
-                    examine_cluster(slots, idx_map, a.n_large_slots + (g0 + bit) * kClusterStride, lane, p.o.x, p.o.y,
-                                    p.o.z, p.du.x, p.du.y, p.du.z, key[r]);
-                    n_tests += kClusterSize;
+                cm[r] = sl[r].active ? (outside[r] ? ~0u : ~miss[r]) << (32u - jn) : 0u;  // first cluster at bit 31
+                if (sl[r].active) n_tests += jn;
+                packed += static_cast<uint32_t>(__builtin_popcount(cm[r]));
+                DBG_ADD(dbg_cands, __builtin_popcount(cm[r]));
+            }
+            const uint32_t incl = wave_inclusive_sum(packed);  // over the lanes
+            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+            if (total == 0u) continue;
+            if (total > kItemCap) {  // (only when many rays start outside the boxes' range)
+#pragma unroll
+                for (int r = 0; r < R; ++r) walk_clusters(slots, idx_map, a, cm[r], g0, sl[r].p, key[r], n_tests);
+                continue;
+            }
+            {   // my items, at my place in the list
+                uint32_t pos = incl - packed;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    uint32_t m = cm[r];
+                    while (m) {
+                        const uint32_t bit = static_cast<uint32_t>(__builtin_clz(m));
+                        m &= ~(0x80000000u >> bit);
+                        items[pos++] = static_cast<uint16_t>(lane | (static_cast<uint32_t>(r) << 6) | (bit << 7));
+                    }
                 }
             }
-            continue;
+            consume_items(slots, idx_map, a, items, total, g0, sl, results, n_tests, dbg_slow_trips);
+            DBG_ADD(dbg_t_slow, DBG_STAMP() - ts0);
         }
-        {   // my items, at my place in the list: lane | slot << 6 | cluster-in-group << 7
-            uint32_t pos = incl - packed;
+    } else {
+        // ---- large scenes: super-cluster boxes in lock-step (32 at a time: 256 clusters), then the
+        // cluster boxes of the (ray, super-cluster) pairs that pass, one pair per lane, then the members ----
+        const float4* sbounds = bounds + 2u * a.n_clusters;
+        uint16_t* sitems = items + kItemCap;
+        for (uint32_t s0 = 0; s0 < a.n_super; s0 += 32u) {
+            uint32_t miss[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) miss[r] = 0u;
+            const uint32_t jn = a.n_super - s0 < 32u ? a.n_super - s0 : 32u;
+            for (uint32_t j = 0; j < jn; ++j) {
+                const float4 mid = sbounds[2u * (s0 + j)], half = sbounds[2u * (s0 + j) + 1u];  // LDS broadcast
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    miss[r] = __builtin_amdgcn_alignbit(
+                        miss[r], __float_as_uint(slab_gap(mid, half, ix[r], iy[r], iz[r], ax[r], ay[r], az[r])), 31);
+            }
+            [[maybe_unused]] const unsigned long long ts0 = DBG_STAMP();
+            uint32_t sm[R];
+            uint32_t packed = 0u;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                uint32_t m = cm[r];
-                while (m) {
-                    const uint32_t bit = static_cast<uint32_t>(__builtin_clz(m));
-                    m &= ~(0x80000000u >> bit);
-                    items[pos++] = static_cast<uint16_t>(lane | (static_cast<uint32_t>(r) << 6) | (bit << 7));
+                sm[r] = sl[r].active ? (outside[r] ? ~0u : ~miss[r]) << (32u - jn) : 0u;  // first super-cluster at bit 31
+                if (sl[r].active) n_tests += jn;
+                packed += static_cast<uint32_t>(__builtin_popcount(sm[r]));
+            }
+            const uint32_t incl = wave_inclusive_sum(packed);
+            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+            if (total == 0u) continue;
+            if (total > kItemCap) {  // (many rays outside the boxes' range) every cluster of every candidate, lane by lane
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    uint32_t m = sm[r];
+                    while (m) {
+                        const uint32_t bit = static_cast<uint32_t>(__builtin_clz(m));
+                        m &= ~(0x80000000u >> bit);
+                        walk_clusters(slots, idx_map, a, 0xFF000000u, (s0 + bit) * kSuperSize, sl[r].p, key[r], n_tests);
+                    }
+                }
+                continue;
+            }
+            {
+                uint32_t pos = incl - packed;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    uint32_t m = sm[r];
+                    while (m) {
+                        const uint32_t bit = static_cast<uint32_t>(__builtin_clz(m));
+                        m &= ~(0x80000000u >> bit);
+                        sitems[pos++] = static_cast<uint16_t>(lane | (static_cast<uint32_t>(r) << 6) | (bit << 7));
+                    }
                 }
             }
-        }
-        // a wave's LDS operations are performed in order: the list is complete for the reads below
-        for (uint32_t k0 = 0; k0 < total; k0 += 64u) {
-            DBG_ADD(dbg_slow_trips, lane == 0u ? 1u : 0u);
-            const bool valid = k0 + lane < total;
-            const uint32_t item = valid ? items[k0 + lane] : 0u;
-            const int src = static_cast<int>(item & 63u);
-            const bool second = (item & 64u) != 0u;
-            static_assert(R == 2, "the work list encodes the path slot in one bit");
-            const float ox0 = __shfl(sl[0].p.o.x, src), oy0 = __shfl(sl[0].p.o.y, src), oz0 = __shfl(sl[0].p.o.z, src);
-            const float dx0 = __shfl(sl[0].p.du.x, src), dy0 = __shfl(sl[0].p.du.y, src), dz0 = __shfl(sl[0].p.du.z, src);
-            const float ox1 = __shfl(sl[1].p.o.x, src), oy1 = __shfl(sl[1].p.o.y, src), oz1 = __shfl(sl[1].p.o.z, src);
-            const float dx1 = __shfl(sl[1].p.du.x, src), dy1 = __shfl(sl[1].p.du.y, src), dz1 = __shfl(sl[1].p.du.z, src);
-            if (valid) {
-                unsigned long long k2 = ~0ull;
-                examine_cluster(slots, idx_map, a.n_large_slots + (g0 + (item >> 7)) * kClusterStride, lane,
-                                second ? ox1 : ox0, second ? oy1 : oy0, second ? oz1 : oz0, second ? dx1 : dx0,
-                                second ? dy1 : dy0, second ? dz1 : dz0, k2);
-                n_tests += kClusterSize;
-                if (k2 != ~0ull) atomicMin(&results[(item & 127u)], k2);  // ds_min_u64; slot * 64 + lane
+            uint32_t pending = 0u;  // (ray, cluster) items in `items`
+            for (uint32_t k0 = 0; k0 < total; k0 += 64u) {
+                const bool valid = k0 + lane < total;
+                const uint32_t item = valid ? sitems[k0 + lane] : 0u;
+                float ox, oy, oz, dx, dy, dz;
+                fetch_item_ray(sl, item, ox, oy, oz, dx, dy, dz);
+                uint32_t hit8 = 0u;  // bit k: cluster k of the super-cluster
+                if (valid) {
+                    const float jx = slab_rcp(dx), jy = slab_rcp(dy), jz = slab_rcp(dz);
+                    const float bx = -ox * jx, by = -oy * jy, bz = -oz * jz;
+                    const float qx = ox - a.ccenter[0], qy = oy - a.ccenter[1], qz = oz - a.ccenter[2];
+                    const bool out = !(fma_(qz, qz, fma_(qy, qy, qx * qx)) <= a.crmax2);
+                    const uint32_t first = (s0 + (item >> 7)) * kSuperSize;
+#pragma unroll
+                    for (uint32_t j = 0; j < kSuperSize; ++j) {
+                        const uint32_t k = (j + lane) & (kSuperSize - 1u);  // lane-rotated: spreads the LDS banks
+                        const float4 mid = bounds[2u * (first + k)], half = bounds[2u * (first + k) + 1u];
+                        const bool reach = !__builtin_signbit(slab_gap(mid, half, jx, jy, jz, bx, by, bz));
+                        hit8 |= (reach ? 1u : 0u) << k;
+                    }
+                    if (out) hit8 = (1u << kSuperSize) - 1u;
+                    n_tests += kSuperSize;
+                    DBG_ADD(dbg_cands, __builtin_popcount(hit8));
+                }
+                const uint32_t cnt = static_cast<uint32_t>(__builtin_popcount(hit8));
+                const uint32_t incl2 = wave_inclusive_sum(cnt);
+                const uint32_t tot2 = __builtin_amdgcn_readlane(incl2, 63);  // <= 64 * 8 = kItemCap
+                if (pending + tot2 > kItemCap) {
+                    consume_items(slots, idx_map, a, items, pending, s0 * kSuperSize, sl, results, n_tests, dbg_slow_trips);
+                    pending = 0u;
+                }
+                uint32_t pos = pending + incl2 - cnt;
+                while (hit8) {
+                    const uint32_t k = static_cast<uint32_t>(__builtin_ctz(hit8));
+                    hit8 &= hit8 - 1u;
+                    items[pos++] = static_cast<uint16_t>((item & 127u) | (((item >> 7) * kSuperSize + k) << 7));
+                }
+                pending += tot2;
             }
+            consume_items(slots, idx_map, a, items, pending, s0 * kSuperSize, sl, results, n_tests, dbg_slow_trips);
+            DBG_ADD(dbg_t_slow, DBG_STAMP() - ts0);
         }
-        DBG_ADD(dbg_t_slow, DBG_STAMP() - ts0);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -982,21 +1111,21 @@ constexpr int kAccelMaxThreads = RTIOW_ACCEL_MAX_THREADS;  // the clustered kern
 template <bool SHADE_LDS, bool ACCEL>
 __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persistent_kernel(PathArgs a, PersistArgs g) {
     // LDS: sphere list [g.n_pad float4] — the flat list, or (ACCEL) the clustered list's slots, then
-    // (ACCEL) the slots' original indices [g.n_pad u32] and the cluster boxes [2 a.n_clusters float4];
+    // (ACCEL) the slots' original indices [g.n_pad u32] and the boxes [2 (a.n_clusters + a.n_super) float4];
     // then (SHADE_LDS) two float4 of shading record per sphere; then the accumulator entries of every
     // wave of the workgroup (a wave allocates only from its own 64); then the tail pool:
     // {parked, arrived, published, pad} + kTailPool records.
     extern __shared__ float4 lds_spheres[];
     uint32_t* lds_cidx = reinterpret_cast<uint32_t*>(lds_spheres + g.n_pad);
     float4* lds_cbounds = reinterpret_cast<float4*>(lds_cidx + (ACCEL ? g.n_pad : 0u));
-    float4* lds_shade = lds_cbounds + (ACCEL ? 2u * a.n_clusters : 0u);
+    float4* lds_shade = lds_cbounds + (ACCEL ? 2u * (a.n_clusters + a.n_super) : 0u);
     unsigned long long* lds_acc = reinterpret_cast<unsigned long long*>(lds_shade + (SHADE_LDS ? 2u * a.n : 0u));
     const uint32_t waves_in_group = blockDim.x / 64u;
     const uint32_t wave_in_group = threadIdx.x / 64u;
     uint32_t* lds_tail = reinterpret_cast<uint32_t*>(lds_acc + waves_in_group * (kWaveAccBytes / 8u));
     // (ACCEL) per wave: the phase-2 work list and result keys of trace_clustered
     [[maybe_unused]] unsigned long long* lds_results = reinterpret_cast<unsigned long long*>(
-        reinterpret_cast<unsigned char*>(lds_tail) + kTailBytes + wave_in_group * kWaveItemBytes);
+        reinterpret_cast<unsigned char*>(lds_tail) + kTailBytes + wave_in_group * wave_item_bytes(a.n_super != 0u));
     [[maybe_unused]] uint16_t* lds_items = reinterpret_cast<uint16_t*>(lds_results + 128);
     if (threadIdx.x < 4u) lds_tail[threadIdx.x] = 0u;
     if (ACCEL) {
@@ -1004,7 +1133,7 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
             lds_spheres[i] = a.cslots[i];
             lds_cidx[i] = a.cidx[i];
         }
-        for (uint32_t i = threadIdx.x; i < 2u * a.n_clusters; i += blockDim.x) lds_cbounds[i] = a.cbounds[i];
+        for (uint32_t i = threadIdx.x; i < 2u * (a.n_clusters + a.n_super); i += blockDim.x) lds_cbounds[i] = a.cbounds[i];
     } else {
         stage_spheres(a, lds_spheres, g.n_pad);
     }
@@ -1416,8 +1545,9 @@ hipError_t launch_ch(const ChArgs& a, hipStream_t stream) {
 static bool use_persistent(uint32_t kernel) { return kernel != KERNEL_PIXEL; }
 constexpr uint32_t kClusteredFrom = 64;  // spheres; below, boxes + one cluster cost more than the flat scan
 
-hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, int num_cus,
+hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take, int num_cus,
                        hipStream_t stream, uint32_t* resolved) {
+    PathArgs a = args;
     if (!use_persistent(kernel)) {
         *resolved = KERNEL_PIXEL;
         const uint32_t tiles = ((a.width + 15u) / 16u) * ((a.local_rows + 15u) / 16u);
@@ -1434,10 +1564,15 @@ hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, in
     // flat list; frames are byte-identical either way), the flat list for the handful-of-spheres scenes
     bool accel = kernel == KERNEL_CLUSTERED || (kernel == KERNEL_DEFAULT && a.n >= kClusteredFrom);
     constexpr size_t kLdsPerCu = 160u * 1024u;
-    // the clustered list of the very largest scenes does not fit beside four waves' buffers: flat list then
-    if (accel && static_cast<size_t>(a.n_cslots) * 20u + static_cast<size_t>(a.n_clusters) * 32u +
-                         4u * (kWaveAccBytes + kWaveItemBytes) + kTailBytes > kLdsPerCu)
-        accel = false;
+    // The clustered list must fit the LDS beside four waves' buffers.  The very largest scenes give up
+    // the super-cluster level first (its boxes and second work list), then fall back to the flat list.
+    auto clustered_fits = [&](uint32_t n_super) {
+        return static_cast<size_t>(a.n_cslots) * 20u + static_cast<size_t>(a.n_clusters + n_super) * 32u +
+                   4u * (kWaveAccBytes + wave_item_bytes(n_super != 0u)) + kTailBytes <= kLdsPerCu;
+    };
+    if (accel && !clustered_fits(a.n_super)) a.n_super = 0u;
+    if (accel && !clustered_fits(0u)) accel = false;
+    const uint32_t item_bytes = wave_item_bytes(a.n_super != 0u);
     *resolved = accel ? KERNEL_CLUSTERED : KERNEL_PERSISTENT;
     PersistArgs g{};
     // slots of the LDS sphere list: the flat list padded to whole candidate words, or the clustered one
@@ -1446,7 +1581,7 @@ hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, in
     g.total_pix = a.local_rows * a.width;
     // tests a segment costs, roughly: the whole list, or large spheres + boxes (14 of 11 instructions)
     // + 1.4 clusters of 16 at half the lane efficiency
-    const uint32_t seg_cost = accel ? a.n_large + a.n_clusters * 14u / 11u + 44u : a.n;
+    const uint32_t seg_cost = accel ? a.n_large + (a.n_super ? a.n_super + 24u : a.n_clusters) * 14u / 11u + 44u : a.n;
     uint32_t pool_samples = kPoolWork / (seg_cost < 1u ? 1u : seg_cost);
     pool_samples = pool_samples < 256u ? 256u : (pool_samples > 4096u ? 4096u : pool_samples);
     g.pool_pix = pool_samples / a.spp;  // a few pixels per pool; one pixel when spp is large
@@ -1456,11 +1591,11 @@ hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, in
     // 2 KiB of pixel accumulator entries per wave (clustered: + 3 KiB of work list and result keys) and
     // the 7 KiB tail pool.
     const size_t lds_geo = static_cast<size_t>(g.n_pad) * sizeof(float4) +
-                           (accel ? static_cast<size_t>(g.n_pad) * 4u + static_cast<size_t>(a.n_clusters) * 32u : 0u);
+                           (accel ? static_cast<size_t>(g.n_pad) * 4u + static_cast<size_t>(a.n_clusters + a.n_super) * 32u : 0u);
     const bool shade_lds = lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 28u * 1024u &&
                            !getenv("RTIOW_DEBUG_NO_SHADE_LDS");  // (tuning only)
     const size_t lds_scene = lds_geo + (shade_lds ? static_cast<size_t>(a.n) * sizeof(ShadeRec) : 0u);
-    const size_t lds_wave = kWaveAccBytes + (accel ? kWaveItemBytes : 0u);
+    const size_t lds_wave = kWaveAccBytes + (accel ? item_bytes : 0u);
     void (*kernel_fn)(PathArgs, PersistArgs) =
         accel ? (shade_lds ? path_persistent_kernel<true, true> : path_persistent_kernel<false, true>)
               : (shade_lds ? path_persistent_kernel<true, false> : path_persistent_kernel<false, false>);
