@@ -31,7 +31,7 @@ def _random_scene(rng, n, scale):
 @pytest.mark.parametrize("case", range(20))
 def test_random_scene_all_kernels(gpu_ctx, oracle, case):
     rng = np.random.default_rng(1000 + case)
-    n = int(rng.choice([1, 2, 7, 33, 100, 257, 700, 1500]))
+    n = int(rng.choice([1, 2, 7, 33, 100, 257, 700, 2200]))   # 2200: beyond 96 clusters, super-clusters
     scale = float(rng.choice([0.01, 1.0, 1.0, 50.0, 3000.0]))
     sph, mat = _random_scene(rng, n, scale)
     w, h = int(rng.integers(9, 90)), int(rng.integers(5, 60))
@@ -75,11 +75,11 @@ def test_default_kernel_choice(gpu_ctx):
     assert gpu_ctx.last_kernel() == V.KERNEL_PERSISTENT
 
 
-@pytest.mark.parametrize("n", [40, 330, 1400])
+@pytest.mark.parametrize("n", [40, 330, 1700])
 def test_rays_from_outside_the_box_range(gpu_ctx, oracle, n):
     """A tight knot of spheres on a huge ground, wide camera: most bounces start on the ground far
     outside the range the cluster boxes are inflated for (2 scene diagonals) and must walk every
-    cluster; with 330 spheres a wave's pooled work list overflows and each lane walks its own; with 1400
+    cluster; with 330 spheres a wave's pooled work list overflows and each lane walks its own; with 1700
     the scene has super-clusters and it is their list that overflows."""
     rng = np.random.default_rng(77 + n)
     sph = np.zeros(n + 1, V.SPHERE_DTYPE)
