@@ -399,9 +399,10 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 // Every lane owns kSlots path slots; one loop iteration traces exactly one
 // segment per live slot.
 //
-//   refill   two-level queue.  The global queue hands out pools of consecutive
-//            pixels (one atomicAdd per wave per pool; a single head word
-//            saturates near 90 dequeues/us, far below one dequeue per lane).
+//   refill   two-level queue.  Eight global queues, one per XCD, each head on its
+//            own cache line, hand out pools of consecutive pixels (one atomicAdd
+//            per wave per pool; a line saturates near 90 atomics/us, far below
+//            one dequeue per lane).
 //            A wave walks its pool pixel by pixel, sample by sample: the idle
 //            slots of the wave are found with __ballot, ranked with mbcnt and
 //            given consecutive samples of the current pixel, no memory traffic.
@@ -411,7 +412,8 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 //            branch-free: the sign bit of each discriminant is shifted into a
 //            per-lane candidate word by one v_alignbit.  Only candidates (about
 //            two per ray) take the sqrt/root path, per lane, after each block of
-//            32 spheres.
+//            32 spheres.  (ACCEL: the two-level clustered list instead, see
+//            trace_clustered; the rest of the kernel is shared.)
 //   sparse   path lengths are heavy-tailed (mean 2.8 segments, 0.1 % reach depth 50
 //            inside glass), so once the queue is empty a wave is left with a
 //            handful of long paths, and a lock-step iteration costs the same for
