@@ -254,6 +254,11 @@ class Context:
                                               None), "rtRenderUbo")
         return out
 
+    def render_ubo_device(self, ubo: RtUbo5, mode: int, dst_ptr: int, pitch: int, stream: int = 0) -> None:
+        """The reference's dispatch (20-byte UBO in, RGBA8 image out) into device memory, no host sync."""
+        _check(self._h, self._lib.rtRenderUbo(self._h, C.byref(ubo), mode, _VP(dst_ptr), pitch, 1,
+                                              _VP(stream) if stream else None), "rtRenderUbo")
+
     def synchronize(self) -> None:
         _check(self._h, self._lib.rtSynchronize(self._h), "rtSynchronize")
 
