@@ -686,10 +686,10 @@ DI void examine_cluster(const float4* slots, const uint32_t* idx_map, uint32_t b
         const float disc = fma_(hb, hb, -cc);
         mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(disc), 31);
     }
-    uint32_t cand = ~mm & 0xFFFFu;  // bit 15-k: member step k
+    uint32_t cand = ~mm & (0xFFFFFFFFu >> (32u - kClusterSize));  // bit kClusterSize-1-k: member step k
     while (cand) {
-        const uint32_t k = static_cast<uint32_t>(__builtin_clz(cand)) - 16u;
-        cand &= ~(0x8000u >> k);
+        const uint32_t k = static_cast<uint32_t>(__builtin_clz(cand)) - (32u - kClusterSize);
+        cand &= ~((1u << (kClusterSize - 1u)) >> k);
         examine_keyed(slots, idx_map, base + ((k + lane) & (kClusterSize - 1u)), ox, oy, oz, dx, dy, dz, key);
     }
 }
@@ -1070,18 +1070,20 @@ DI void trace_sparse_clustered(const float4* slots, const uint32_t* idx_map, con
                     ++n_tests;
                 }
                 unsigned long long todo = __ballot(reach);
-                while (todo != 0ull) {  // four clusters per pass, one member per lane
-                    int c[4];
+                while (todo != 0ull) {  // 64 / kClusterSize clusters per pass, one member per lane
+                    constexpr uint32_t kPerPass = 64u / kClusterSize;
+                    const uint32_t q = lane / kClusterSize;
+                    int mine = -1;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        c[q] = todo != 0ull ? __builtin_ctzll(todo) : -1;
+                    for (uint32_t t = 0; t < kPerPass; ++t) {
+                        const int c = todo != 0ull ? __builtin_ctzll(todo) : -1;
                         todo &= todo - 1ull;   // (0 stays 0)
+                        mine = q == t ? c : mine;
                     }
-                    const uint32_t q = lane >> 4;
-                    const int mine = q == 0u ? c[0] : (q == 1u ? c[1] : (q == 2u ? c[2] : c[3]));
                     if (mine >= 0) {
                         examine_keyed(slots, idx_map,
-                                      a.n_large_slots + (g0 + static_cast<uint32_t>(mine)) * kClusterStride + (lane & 15u),
+                                      a.n_large_slots + (g0 + static_cast<uint32_t>(mine)) * kClusterStride +
+                                          (lane & (kClusterSize - 1u)),
                                       ox, oy, oz, dx, dy, dz, key);
                         ++n_tests;
                     }
