@@ -824,6 +824,7 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
         uint32_t miss[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) miss[r] = 0u;
+#pragma unroll 4
         for (uint32_t j = 0; j < jn; ++j) {
             const float4 s = slots[base + j];  // wave-uniform address: LDS broadcast
 #pragma unroll
