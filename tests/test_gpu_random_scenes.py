@@ -54,20 +54,31 @@ def test_random_scene_all_kernels(gpu_ctx, oracle, case):
 
 
 def test_default_kernel_choice(gpu_ctx):
-    """RtParams.kernel 0: clustered list from 64 spheres on, flat list for small scenes and for a camera
-    outside the range the cluster boxes were sized for; an explicit choice is honoured."""
+    """RtParams.kernel 0: clustered list from 64 spheres on, flat list for small scenes; an explicit choice
+    is honoured.  A camera outside the range the cluster boxes were sized for has them re-boxed with wider
+    margins (and re-boxed again when it comes back); only an absurdly distant one gets the flat list."""
     sph, mat = V.make_cover_scene(1, 11)
     gpu_ctx.set_scene(sph, mat)
     near = V.make_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, 1.5, 0.1, 10.0)
     far = V.make_camera((1300, 200, 300), (0, 0, 0), (0, 1, 0), 1.0, 1.5, 0.0, 10.0)
-    prm = dict(spp=1, max_depth=4, seed=3)
+    absurd = V.make_camera((130000, 20000, 30000), (0, 0, 0), (0, 1, 0), 0.01, 1.5, 0.0, 10.0)
+    prm = dict(spp=2, max_depth=6, seed=3)
     a = gpu_ctx.render(near, V.make_params(48, 32, **prm))
     assert gpu_ctx.last_kernel() == V.KERNEL_CLUSTERED
     b = gpu_ctx.render(near, V.make_params(48, 32, kernel=V.KERNEL_PERSISTENT, **prm))
     assert gpu_ctx.last_kernel() == V.KERNEL_PERSISTENT and np.array_equal(a, b)
     gpu_ctx.render(near, V.make_params(48, 32, kernel=V.KERNEL_PIXEL, **prm))
     assert gpu_ctx.last_kernel() == V.KERNEL_PIXEL
-    gpu_ctx.render(far, V.make_params(48, 32, **prm))
+    f_flat = gpu_ctx.render(far, V.make_params(48, 32, kernel=V.KERNEL_PERSISTENT, **prm))
+    f_clus = gpu_ctx.render(far, V.make_params(48, 32, **prm))          # boxes rebuilt for the far camera
+    st = gpu_ctx.stats()
+    assert gpu_ctx.last_kernel() == V.KERNEL_CLUSTERED and np.array_equal(f_flat, f_clus)
+    assert st.sphere_tests < st.segments * len(sph) // 2
+    a2 = gpu_ctx.render(near, V.make_params(48, 32, **prm))             # and rebuilt again, tight
+    st = gpu_ctx.stats()
+    assert gpu_ctx.last_kernel() == V.KERNEL_CLUSTERED and np.array_equal(a, a2)
+    assert st.sphere_tests < st.segments * len(sph) // 4
+    gpu_ctx.render(absurd, V.make_params(48, 32, **prm))
     assert gpu_ctx.last_kernel() == V.KERNEL_PERSISTENT
     sph3, mat3 = V.make_three_sphere_scene()
     gpu_ctx.set_scene(sph3, mat3)

@@ -10,6 +10,9 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
+#include <cmath>
+#include <algorithm>
 
 #include "../../include/rtiow.h"
 #include "rtiow_device.h"
@@ -28,6 +31,8 @@ struct RtContext {
     float cluster_center[3] = {0, 0, 0};
     float cluster_diag = 0, cluster_rmax2 = 0;
     uint32_t last_kernel = 0;     // variant the last PATH render launched
+    std::vector<RtSphere> host_spheres;  // kept to re-box the clusters for a camera farther out
+    double cluster_range = 0;     // range_diags the current boxes were built for
     uint32_t n_spheres = 0;
     rtiow::Counters* d_counters = nullptr;
     rtiow::Counters* h_counters = nullptr;  // pinned
@@ -145,6 +150,35 @@ int rtDestroy(RtContext* ctx) {
     return RT_OK;
 }
 
+// Builds the two-level list of the clustered kernel for ray origins up to range_diags scene diagonals
+// from the scene's centre and uploads it (the context's stream must be idle).
+static int upload_clusters(RtContext* ctx, double range_diags) {
+    rtiow::ClusterScene cs;
+    rtiow::build_clusters(ctx->host_spheres.data(), static_cast<uint32_t>(ctx->host_spheres.size()), range_diags, cs);
+    if (ctx->d_cslots) RT_HIP(ctx, hipFree(ctx->d_cslots));
+    if (ctx->d_cidx) RT_HIP(ctx, hipFree(ctx->d_cidx));
+    if (ctx->d_cbounds) RT_HIP(ctx, hipFree(ctx->d_cbounds));
+    ctx->d_cslots = nullptr;
+    ctx->d_cidx = nullptr;
+    ctx->d_cbounds = nullptr;
+    RT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_cslots), sizeof(float4) * cs.slots.size()));
+    RT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_cidx), sizeof(uint32_t) * cs.idx.size()));
+    RT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_cbounds), sizeof(float4) * cs.bounds.size()));
+    RT_HIP(ctx, hipMemcpy(ctx->d_cslots, cs.slots.data(), sizeof(float4) * cs.slots.size(), hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemcpy(ctx->d_cidx, cs.idx.data(), sizeof(uint32_t) * cs.idx.size(), hipMemcpyHostToDevice));
+    RT_HIP(ctx, hipMemcpy(ctx->d_cbounds, cs.bounds.data(), sizeof(float4) * cs.bounds.size(), hipMemcpyHostToDevice));
+    ctx->n_clusters = cs.n_clusters;
+    ctx->n_super = cs.n_super;
+    ctx->n_large = cs.n_large;
+    ctx->n_large_slots = cs.n_large_slots;
+    ctx->n_cslots = static_cast<uint32_t>(cs.slots.size());
+    for (int k = 0; k < 3; ++k) ctx->cluster_center[k] = cs.center[k];
+    ctx->cluster_diag = cs.diag;
+    ctx->cluster_rmax2 = cs.rmax2;
+    ctx->cluster_range = range_diags < 2.0 ? 2.0 : range_diags;
+    return RT_OK;
+}
+
 int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materials,
                uint32_t n_spheres) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rtSetScene: ctx is null");
@@ -192,29 +226,9 @@ int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materi
     delete[] tmp;
     if (e != hipSuccess) return fail_hip(ctx, e, "hipMemcpy(shading records)");
     RT_HIP(ctx, hipMemcpy(ctx->d_spheres, spheres, sizeof(float4) * n_spheres, hipMemcpyHostToDevice));
-    // two-level list for the clustered kernel
-    rtiow::ClusterScene cs;
-    rtiow::build_clusters(spheres, n_spheres, cs);
-    if (ctx->d_cslots) RT_HIP(ctx, hipFree(ctx->d_cslots));
-    if (ctx->d_cidx) RT_HIP(ctx, hipFree(ctx->d_cidx));
-    if (ctx->d_cbounds) RT_HIP(ctx, hipFree(ctx->d_cbounds));
-    ctx->d_cslots = nullptr;
-    ctx->d_cidx = nullptr;
-    ctx->d_cbounds = nullptr;
-    RT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_cslots), sizeof(float4) * cs.slots.size()));
-    RT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_cidx), sizeof(uint32_t) * cs.idx.size()));
-    RT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_cbounds), sizeof(float4) * cs.bounds.size()));
-    RT_HIP(ctx, hipMemcpy(ctx->d_cslots, cs.slots.data(), sizeof(float4) * cs.slots.size(), hipMemcpyHostToDevice));
-    RT_HIP(ctx, hipMemcpy(ctx->d_cidx, cs.idx.data(), sizeof(uint32_t) * cs.idx.size(), hipMemcpyHostToDevice));
-    RT_HIP(ctx, hipMemcpy(ctx->d_cbounds, cs.bounds.data(), sizeof(float4) * cs.bounds.size(), hipMemcpyHostToDevice));
-    ctx->n_clusters = cs.n_clusters;
-    ctx->n_super = cs.n_super;
-    ctx->n_large = cs.n_large;
-    ctx->n_large_slots = cs.n_large_slots;
-    ctx->n_cslots = static_cast<uint32_t>(cs.slots.size());
-    for (int k = 0; k < 3; ++k) ctx->cluster_center[k] = cs.center[k];
-    ctx->cluster_diag = cs.diag;
-    ctx->cluster_rmax2 = cs.rmax2;
+    ctx->host_spheres.assign(spheres, spheres + n_spheres);
+    int rc = upload_clusters(ctx, 2.0);
+    if (rc != RT_OK) return rc;
     ctx->n_spheres = n_spheres;
     return RT_OK;
 }
@@ -316,9 +330,12 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         a.dst = out;
         a.dst_stride = out_stride;
         a.counters = ctx->d_counters;
-        // The cluster boxes are inflated for ray origins within 2 scene diagonals of the scene's centre
-        // (rtiow_clusters.cpp); the kernel sends any ray that starts farther out through every cluster.
-        // A camera out there would do that for all its primary rays: it gets the flat list instead.
+        // The cluster boxes are inflated for ray origins within cluster_range scene diagonals of the
+        // scene's centre (rtiow_clusters.cpp); the kernel sends any ray that starts farther out through
+        // every cluster.  A camera out there would do that for all its primary rays: the boxes are rebuilt
+        // for twice its distance (wider margins; rare, so the streams are simply drained first), and again
+        // once the camera has come back to an eighth of that range.  Beyond 64
+        // diagonals the margins swallow the boxes: flat list.
         uint32_t kernel = prm->kernel;
         if (kernel == rtiow::KERNEL_CLUSTERED || kernel == rtiow::KERNEL_DEFAULT) {
             double d2 = 0.0;
@@ -326,8 +343,24 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
                 const double d = double(cam->origin[k]) - double(ctx->cluster_center[k]);
                 d2 += d * d;
             }
-            const double reach = 1.9 * double(ctx->cluster_diag) - double(cam->lens_radius);
-            if (!(reach > 0.0 && d2 <= reach * reach)) kernel = rtiow::KERNEL_PERSISTENT;
+            const double need = (std::sqrt(d2) + double(cam->lens_radius)) / std::max(1e-30, double(ctx->cluster_diag));
+            if (!(need <= 64.0)) {
+                kernel = rtiow::KERNEL_PERSISTENT;
+            } else if (need > 0.95 * ctx->cluster_range || (ctx->cluster_range > 2.0 && need < ctx->cluster_range / 8.0)) {
+                RT_HIP(ctx, hipDeviceSynchronize());
+                int rc = upload_clusters(ctx, 2.0 * need);
+                if (rc != RT_OK) return rc;
+                a.cslots = ctx->d_cslots;
+                a.cidx = ctx->d_cidx;
+                a.cbounds = ctx->d_cbounds;
+                a.n_clusters = ctx->n_clusters;
+                a.n_super = ctx->n_super;
+                a.n_large = ctx->n_large;
+                a.n_large_slots = ctx->n_large_slots;
+                a.n_cslots = ctx->n_cslots;
+                for (int k = 0; k < 3; ++k) a.ccenter[k] = ctx->cluster_center[k];
+                a.crmax2 = ctx->cluster_rmax2;
+            }
         }
         RT_HIP(ctx, rtiow::launch_path(a, kernel, prm->chunk_spp, ctx->num_cus, stream, &ctx->last_kernel));
     }

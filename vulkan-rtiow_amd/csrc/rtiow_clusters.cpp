@@ -15,8 +15,9 @@
 //     hb^2 - (|oc|^2 - r^2) with an absolute error below ~22 eps |oc|^2 (eps = 2^-24),
 //     so a ray the exact test accepts passes within sqrt(r^2 + E) of the centre, E = 48 eps |oc|max^2.
 //     Every member is boxed with that radius plus the slab test's own rounding (a shift of the planes
-//     by a few eps of the coordinates), for ray origins within rmax = 2 diag of the scene's centre;
-//     the kernel sends a ray that starts farther out through all clusters.
+//     by a few eps of the coordinates), for ray origins within rmax of the scene's centre (2 scene
+//     diagonals, more when the camera stands farther out: range_diags); the kernel sends a ray that
+//     starts beyond rmax through all clusters.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -35,7 +36,7 @@ float round_up(double v) {  // smallest float >= v
 }
 }  // namespace
 
-void build_clusters(const RtSphere* sph, uint32_t n, ClusterScene& out) {
+void build_clusters(const RtSphere* sph, uint32_t n, double range_diags, ClusterScene& out) {
     out.slots.clear();
     out.idx.clear();
     out.bounds.clear();
@@ -65,12 +66,12 @@ void build_clusters(const RtSphere* sph, uint32_t n, ClusterScene& out) {
     const double diag = std::sqrt(diag2);
     out.diag = static_cast<float>(diag);
     // rays that start within rmax of the centre use the boxes; |oc| <= rmax + diag/2 for them
-    const double rmax = 2.0 * diag;
+    const double rmax = std::max(2.0, range_diags) * diag;
     out.rmax2 = static_cast<float>(rmax * rmax);
     constexpr double kEps = 5.9604644775390625e-8;  // 2^-24
-    const double oc_max = 2.5 * diag;               // rmax + diag/2, and the rounding of the kernel's own range check
+    const double oc_max = rmax * 1.05 + 0.5 * diag;  // rmax + diag/2, and the rounding of the kernel's own range check
     const double r2_margin = 48.0 * kEps * oc_max * oc_max;
-    const double plane_margin = 64.0 * kEps * (cmax + 3.0 * diag) + 1e-30;
+    const double plane_margin = 64.0 * kEps * (cmax + rmax + diag) + 1e-30;
 
     // Order the small spheres so that every run of kClusterSize is a compact group: split the set at
     // the median of its longest axis, the left part rounded to whole clusters, and recurse.  (Runs of a

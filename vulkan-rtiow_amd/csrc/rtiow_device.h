@@ -97,10 +97,11 @@ struct ClusterScene {  // host-side result of build_clusters
     uint32_t n_large = 0, n_large_slots = 0;
     float center[3] = {0, 0, 0};  // of the clustered spheres
     float diag = 0;               // their extent
-    float rmax2 = 0;              // (2 diag)^2: ray origins farther from the centre are outside the
-                                  // rounding margin the boxes were inflated for
+    float rmax2 = 0;              // (range_diags diag)^2: ray origins farther from the centre are outside
+                                  // the rounding margin the boxes were inflated for
 };
-void build_clusters(const RtSphere* spheres, uint32_t n, ClusterScene& out);
+// range_diags: ray origins up to this many scene diagonals from the scene's centre use the boxes (>= 2)
+void build_clusters(const RtSphere* spheres, uint32_t n, double range_diags, ClusterScene& out);
 
 enum : uint32_t {
     KERNEL_DEFAULT = 0,
