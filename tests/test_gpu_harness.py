@@ -1,6 +1,7 @@
 """GPU (-m gpu): the C++ host harness (the stand-in for RTCHAP06/main.cpp's loop) end to end."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -45,3 +46,17 @@ def test_harness_scene_file_progressive_matches_oracle(oracle, tmp_path):
     cam = oracle.make_camera((-2, 2, 1), (0, 0, -1), (0, 1, 0), 40.0, w / h, 0.05, 3.4)
     want, _ = oracle.render(sph, mat, cam, V.make_params(w, h, spp=12, max_depth=50, seed=1))
     assert np.array_equal(_read_ppm(out), want[::-1, :, :3])
+
+
+def test_library_before_torch_in_one_process():
+    """Loading librtiow_hip.so (and creating a context) before torch first touches the GPU must leave one
+    HIP runtime in the process: the binding preloads the copy of libamdhip64.so that torch ships."""
+    code = ("import vulkan_rtiow_amd as V\n"
+            "c = V.Context(0)\n"
+            "img = c.render_ubo(V.ubo_from_image(64, 48), V.RT_MODE_CH06)\n"
+            "import torch\n"
+            "x = torch.ones(8, device='cuda:0')\n"
+            "print('ok', int(x.sum().item()), img.shape)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "ok 8 (48, 64, 4)" in res.stdout, res.stderr[-2000:]

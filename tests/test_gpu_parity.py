@@ -211,6 +211,33 @@ def test_device_destination_and_pitch(gpu_ctx, oracle):
     assert (host[:, w:] == 0x7F).all()   # padding untouched
 
 
+def test_frames_in_flight_on_three_contexts(gpu_ctx, oracle):
+    """Three contexts with different scenes and cameras render concurrently on their own streams (what
+    bench.py does per rank at N > 1, and what the reference's per-swapchain-image command buffers do,
+    RTCHAP06/main.cpp:94-98): every frame equals the one the context renders alone."""
+    torch = pytest.importorskip("torch")
+    w, h = 160, 90
+    jobs = []
+    for k, (name, spp) in enumerate([("cover11", 6), ("three", 9), ("cover5", 3)]):
+        sph, mat, cam = _case(oracle, name, w, h)
+        prm = V.make_params(w, h, spp=spp, max_depth=12, seed=20 + k)
+        gpu_ctx.set_scene(sph, mat)
+        alone = gpu_ctx.render(cam, prm)
+        ctx = V.Context(0)
+        ctx.set_scene(sph, mat)
+        jobs.append((ctx, cam, prm, alone, torch.cuda.Stream(),
+                     [torch.zeros((h, w), dtype=torch.int32, device="cuda:0") for _ in range(4)]))
+    torch.cuda.synchronize()
+    for rnd in range(4):            # 12 frames in flight over three streams
+        for ctx, cam, prm, _, ts, bufs in jobs:
+            ctx.render_device(cam, prm, bufs[rnd].data_ptr(), w * 4, ts.cuda_stream)
+    torch.cuda.synchronize()
+    for ctx, _, _, alone, _, bufs in jobs:
+        for b in bufs:
+            assert np.array_equal(b.cpu().numpy().view(np.uint8).reshape(h, w, 4), alone)
+        ctx.close()
+
+
 def test_error_behaviour(gpu_ctx, oracle):
     lib = V.load_library()
     fresh = V.Context(0)

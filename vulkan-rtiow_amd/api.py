@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -100,6 +101,26 @@ class RtError(RuntimeError):
         self.code = code
 
 
+def _share_torch_hip_runtime() -> None:
+    """PyTorch wheels carry their own libamdhip64.so (same SONAME as /opt/rocm's, different file) and
+    ask for it by the name `libamdhip64.so`.  If this library is loaded first it binds /opt/rocm's
+    copy, torch later loads its own as a second HIP runtime in the process, and that one finds no GPU.
+    Loading torch's copy first (by path, without importing torch) lets both bind the same runtime,
+    whichever of the two is imported first."""
+    if "torch" in sys.modules:
+        return  # already loaded: our libamdhip64.so.7 resolves to torch's copy by SONAME
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # no torch, or an unusual layout: /opt/rocm's runtime is used
+        pass
+
+
 def load_library(path: str = LIB_PATH) -> C.CDLL:
     """Loads librtiow_hip.so and types every exported entry point.  Raises if it is absent."""
     global _lib
@@ -109,6 +130,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         raise ImportError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the render path.")
+    _share_torch_hip_runtime()
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
