@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector (= f32 MFMA rate)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.53  # wave instructions / s: profiles/r01_ubench_valu.txt (v_fma_f32, 8 blocks/CU)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FLOPS_PER_TEST = 16             # oc 3, hb 5, cc 6, disc 2 (unit direction: a == 1)
 FLOPS_PER_SEGMENT_SHADE = 60
@@ -230,6 +231,22 @@ def main():
                 if tj.get("workload") == args.workload and tj.get("bench_kernel") == KERNEL_NAMES.get(eff_kernel):
                     traffic = tj.get("hbm_bytes_per_launch")
                     break
+        # VALU issue utilisation of the same kernel from the committed PMC profile (SQ_INSTS_VALU per launch)
+        # against the issue rate tools/ubench_valu.hip measures for back-to-back v_fma_f32 on this part
+        # (2.53 cycles per wave instruction per SIMD at 2.4 GHz: 0.97e12 wave instructions / s)
+        valu_issue = None
+        pmc_name = {2: "path_persistent_kernel<true,false>", 3: "path_persistent_kernel<true,true>"}.get(eff_kernel)
+        if world == 1 and pmc_name and args.workload == "cover_1200x800_100spp":
+            for ppath in ("r01_pmc.json", "r01f_pmc.json"):
+                try:
+                    pj = json.load(open(os.path.join(ROOT, "profiles", ppath)))
+                    insts = pj[pmc_name]["SQ_INSTS_VALU"]["mean_per_launch"]
+                    valu_issue = {"valu_wave_instructions_per_launch": insts,
+                                  "rate": insts / (kernel_ms * 1e-3), "peak": VALU_ISSUE_PEAK, "unit": "wave instructions/s",
+                                  "frac": insts / (kernel_ms * 1e-3) / VALU_ISSUE_PEAK, "source": "profiles/" + ppath}
+                    break
+                except (OSError, KeyError, ValueError):
+                    continue
         out = {
             "metric": "Mray/s (w*h*spp*depth / s), cover scene 1200x800", "value": value, "unit": "Mray/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -252,6 +269,7 @@ def main():
                         "(flat list: segments*N; clustered list: large spheres + cluster boxes + members of the boxes "
                         "a ray reaches); kernel time = HIP events on the launch stream over the timed steps",
                 "tests_per_segment": st.sphere_tests / max(1, st.segments),
+                "valu_issue": valu_issue,
                 "flat_list_equivalent": {"achieved": flat_equiv, "frac": flat_equiv / FP32_VALU_PEAK_TFLOPS,
                                          "unit": "TFLOP/s", "note": "segments*(16 N + 60): the flat list's work for "
                                          "the same frame over this kernel's time; above 1 means the acceleration "
