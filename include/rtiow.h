@@ -215,6 +215,11 @@ uint32_t rtTileGlobalRow(uint32_t local_row, uint32_t row_block, uint32_t tile_r
  * PPM "P6", top scene row first, i.e. buffer row H-1 first (rt.frag:8's flip). */
 int rtWritePPM(const char* path, const void* rgba8, uint32_t width, uint32_t height,
                size_t pitch);
+/* The same picture as an 8-bit RGB PNG (zlib "stored" blocks: lossless, uncompressed), for viewers
+ * that do not read PPM; same orientation.  Also stands where saveScreenCap's stbi_write_jpg
+ * (RTCHAP06/Vulkan.cpp:743,761) stood. */
+int rtWritePNG(const char* path, const void* rgba8, uint32_t width, uint32_t height,
+               size_t pitch);
 
 #ifdef __cplusplus
 }

@@ -96,6 +96,39 @@ def test_ppm_writer_matches_oracle(oracle, tmp_path):
     assert a == b and a.startswith(b"P6\n7 13\n255\n")
 
 
+def _decode_png_rgb(data):
+    """Minimal PNG reader for the files rtWritePNG produces (8-bit RGB, filter 0): checks signature and
+    every chunk CRC, inflates IDAT with zlib."""
+    import struct, zlib
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        (crc,) = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+        assert crc == zlib.crc32(typ + body) & 0xFFFFFFFF
+        chunks.append((typ, body))
+        pos += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    w, h, depth, ctype, comp, flt, lace = struct.unpack(">IIBBBBB", chunks[0][1])
+    assert (depth, ctype, comp, flt, lace) == (8, 2, 0, 0, 0)
+    raw = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(h, 1 + 3 * w)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 3)
+
+
+@pytest.mark.parametrize("w,h", [(7, 13), (1, 1), (300, 100)])   # 300x100: 90 100 raw bytes, two stored blocks
+def test_png_writer_round_trip(tmp_path, w, h):
+    rng = np.random.default_rng(w * 1000 + h)
+    img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    V.write_png(str(tmp_path / "a.png"), img)
+    got = _decode_png_rgb((tmp_path / "a.png").read_bytes())
+    assert np.array_equal(got, img[::-1, :, :3])       # top line of the picture = buffer row H-1 (rt.frag:8)
+    lib = V.load_library()
+    assert lib.rtWritePNG(b"/nonexistent-dir/x.png", img.ctypes.data, w, h, w * 4) == V.RT_ERR_IO
+    assert lib.rtWritePNG(None, img.ctypes.data, w, h, w * 4) == V.RT_ERR_INVALID
+
+
 def test_error_codes_without_gpu_or_context():
     lib = V.load_library()
     assert lib.rtRender(None, None, None, None, 0, 0, None) == V.RT_ERR_INVALID

@@ -90,6 +90,7 @@ SIGNATURES = {
     "rtTileRowCount": (C.c_uint32, [C.c_uint32] * 4),
     "rtTileGlobalRow": (C.c_uint32, [C.c_uint32] * 4),
     "rtWritePPM": (C.c_int, [C.c_char_p, _VP, C.c_uint32, C.c_uint32, C.c_size_t]),
+    "rtWritePNG": (C.c_int, [C.c_char_p, _VP, C.c_uint32, C.c_uint32, C.c_size_t]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -199,6 +200,12 @@ def write_ppm(path: str, rgba8: np.ndarray) -> None:
     img = np.ascontiguousarray(rgba8, dtype=np.uint8)
     h, w = img.shape[:2]
     _check(None, load_library().rtWritePPM(os.fsencode(path), img.ctypes.data, w, h, w * 4), "rtWritePPM")
+
+
+def write_png(path: str, rgba8: np.ndarray) -> None:
+    img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    h, w = img.shape[:2]
+    _check(None, load_library().rtWritePNG(os.fsencode(path), img.ctypes.data, w, h, w * 4), "rtWritePNG")
 
 
 def _check(ctx, code: int, where: str) -> None:

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/rtiow.h"
@@ -201,6 +202,92 @@ int rtWritePPM(const char* path, const void* rgba8, uint32_t width, uint32_t hei
         }
         ok = std::fwrite(line.data(), 1, line.size(), f) == line.size();
     }
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? RT_OK : RT_ERR_IO;
+}
+
+namespace {
+uint32_t crc32_update(uint32_t crc, const unsigned char* p, size_t n) {  // PNG chunk CRC (ISO 3309), bitwise table-free
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        ready = true;
+    }
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+    return crc;
+}
+void put_be32(std::vector<unsigned char>& v, uint32_t x) {
+    v.push_back(static_cast<unsigned char>(x >> 24));
+    v.push_back(static_cast<unsigned char>(x >> 16));
+    v.push_back(static_cast<unsigned char>(x >> 8));
+    v.push_back(static_cast<unsigned char>(x));
+}
+bool write_chunk(std::FILE* f, const char type[4], const std::vector<unsigned char>& data) {
+    std::vector<unsigned char> head;
+    put_be32(head, static_cast<uint32_t>(data.size()));
+    head.insert(head.end(), type, type + 4);
+    uint32_t crc = crc32_update(0xFFFFFFFFu, reinterpret_cast<const unsigned char*>(type), 4);
+    crc = crc32_update(crc, data.data(), data.size()) ^ 0xFFFFFFFFu;
+    std::vector<unsigned char> tail;
+    put_be32(tail, crc);
+    return std::fwrite(head.data(), 1, head.size(), f) == head.size() &&
+           (data.empty() || std::fwrite(data.data(), 1, data.size(), f) == data.size()) &&
+           std::fwrite(tail.data(), 1, tail.size(), f) == tail.size();
+}
+}  // namespace
+
+int rtWritePNG(const char* path, const void* rgba8, uint32_t width, uint32_t height, size_t pitch) {
+    if (!path || !rgba8 || width == 0 || height == 0 || pitch < size_t(width) * 4) return RT_ERR_INVALID;
+    // raw scanlines: filter byte 0 + RGB, top line of the picture (buffer row H-1, rt.frag:8) first
+    const size_t line = 1 + size_t(width) * 3;
+    std::vector<unsigned char> raw(line * height);
+    const unsigned char* base = static_cast<const unsigned char*>(rgba8);
+    for (uint32_t y = 0; y < height; ++y) {
+        const unsigned char* row = base + size_t(height - 1 - y) * pitch;
+        unsigned char* dst = raw.data() + line * y;
+        dst[0] = 0;
+        for (uint32_t x = 0; x < width; ++x) {
+            dst[1 + 3 * x + 0] = row[4 * x + 0];
+            dst[1 + 3 * x + 1] = row[4 * x + 1];
+            dst[1 + 3 * x + 2] = row[4 * x + 2];
+        }
+    }
+    // zlib stream of stored deflate blocks (<= 65535 bytes each) + Adler-32
+    std::vector<unsigned char> z;
+    z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+    z.push_back(0x78);
+    z.push_back(0x01);
+    uint32_t s1 = 1, s2 = 0;
+    for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
+        const size_t n = std::min<size_t>(65535, raw.size() - off);
+        z.push_back(off + n >= raw.size() ? 1 : 0);  // BFINAL, BTYPE = 00
+        z.push_back(static_cast<unsigned char>(n & 0xFF));
+        z.push_back(static_cast<unsigned char>(n >> 8));
+        z.push_back(static_cast<unsigned char>(~n & 0xFF));
+        z.push_back(static_cast<unsigned char>((~n >> 8) & 0xFF));
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+        for (size_t i = 0; i < n; ++i) {
+            s1 = (s1 + raw[off + i]) % 65521u;
+            s2 = (s2 + s1) % 65521u;
+        }
+        if (raw.empty()) break;
+    }
+    put_be32(z, (s2 << 16) | s1);
+    std::FILE* f = std::fopen(path, "wb");
+    if (!f) return RT_ERR_IO;
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    bool ok = std::fwrite(sig, 1, 8, f) == 8;
+    std::vector<unsigned char> ihdr;
+    put_be32(ihdr, width);
+    put_be32(ihdr, height);
+    const unsigned char tail[5] = {8, 2, 0, 0, 0};  // 8 bits, colour type 2 (RGB), deflate, filter 0, no interlace
+    ihdr.insert(ihdr.end(), tail, tail + 5);
+    ok = ok && write_chunk(f, "IHDR", ihdr) && write_chunk(f, "IDAT", z) && write_chunk(f, "IEND", {});
     ok = (std::fclose(f) == 0) && ok;
     return ok ? RT_OK : RT_ERR_IO;
 }

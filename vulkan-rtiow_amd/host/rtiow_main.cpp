@@ -4,7 +4,7 @@
 // or taking a JPEG screenshot (Vulkan.cpp:625-766), writes a lossless PPM.
 //
 //   rtiow_main --scene cover|cover4096|three|ch05|ch06|file [--file scene.txt] [--width W --height H
-//              --spp S --depth D --seed N --kernel K --frames F --progressive 0|1 --out file.ppm
+//              --spp S --depth D --seed N --kernel K --frames F --progressive 0|1 --out file.ppm|file.png
 //              --device G]
 //
 // --progressive 1 makes the F frames a running average (RtParams.accumulate): frame f adds spp new
@@ -152,8 +152,10 @@ int main(int argc, char** argv) {
                     f, st.kernel_ms, wall, nominal / (st.kernel_ms * 1e-3) / 1e6,
                     (unsigned long long)st.segments, (unsigned long long)st.sphere_tests);
     }
-    if ((rc = rtWritePPM(out.c_str(), frame.data(), width, height, size_t(width) * 4)) != RT_OK)
-        return die(ctx, "rtWritePPM", rc);
+    const bool png = out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0;
+    rc = png ? rtWritePNG(out.c_str(), frame.data(), width, height, size_t(width) * 4)
+             : rtWritePPM(out.c_str(), frame.data(), width, height, size_t(width) * 4);
+    if (rc != RT_OK) return die(ctx, png ? "rtWritePNG" : "rtWritePPM", rc);
     std::printf("wrote %s\n", out.c_str());
     rtDestroy(ctx);
     return 0;
