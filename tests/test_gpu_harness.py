@@ -28,6 +28,18 @@ def test_harness_ch06_matches_oracle(oracle, tmp_path):
     assert np.array_equal(_read_ppm(out), want[::-1, :, :3])   # the writer flips like rt.frag:8
 
 
+def test_harness_png_output(oracle, tmp_path):
+    """--out x.png: the same picture through rtWritePNG (stored deflate), decoded here with zlib."""
+    import zlib
+    out = str(tmp_path / "ch05.png")
+    subprocess.run([MAIN, "--scene", "ch05", "--width", "160", "--height", "90", "--out", out], check=True)
+    data = open(out, "rb").read()
+    idat = data[data.index(b"IDAT") + 4:data.index(b"IEND") - 8]   # chunk body (CRC and next length cut off)
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(90, 1 + 3 * 160)
+    want = oracle.render_ubo(oracle.ubo_from_image(160, 90), V.RT_MODE_CH05)
+    assert np.array_equal(raw[:, 1:].reshape(90, 160, 3), want[::-1, :, :3])
+
+
 def test_harness_scene_file_progressive_matches_oracle(oracle, tmp_path):
     """scene file + camera line, 3 progressive frames of 4 spp == the oracle at 12 spp."""
     out = str(tmp_path / "demo.ppm")
