@@ -1055,19 +1055,13 @@ DI void trace_sparse_clustered(const float4* slots, const uint32_t* idx_map, con
             }
             const float ix = slab_rcp(dx), iy = slab_rcp(dy), iz = slab_rcp(dz);
             const float ax = -ox * ix, ay = -oy * iy, az = -oz * iz;
-            const float jx = __builtin_fabsf(ix), jy = __builtin_fabsf(iy), jz = __builtin_fabsf(iz);
             const float qx = ox - a.ccenter[0], qy = oy - a.ccenter[1], qz = oz - a.ccenter[2];
             const bool outside = !(fma_(qz, qz, fma_(qy, qy, qx * qx)) <= a.crmax2);
             for (uint32_t g0 = 0; g0 < a.n_clusters; g0 += 64u) {
                 bool reach = false;
                 if (g0 + lane < a.n_clusters) {
                     const float4 mid = bounds[2u * (g0 + lane)], half = bounds[2u * (g0 + lane) + 1u];
-                    const float tcx = fma_(mid.x, ix, ax), tcy = fma_(mid.y, iy, ay), tcz = fma_(mid.z, iz, az);
-                    const float tn = __builtin_fmaxf(__builtin_fmaxf(fma_(-half.x, jx, tcx), fma_(-half.y, jy, tcy)),
-                                                     __builtin_fmaxf(fma_(-half.z, jz, tcz), 0.0f));
-                    const float tf = __builtin_fminf(__builtin_fminf(fma_(half.x, jx, tcx), fma_(half.y, jy, tcy)),
-                                                     fma_(half.z, jz, tcz));
-                    reach = outside || !__builtin_signbit(tf - tn);
+                    reach = outside || !__builtin_signbit(slab_gap(mid, half, ix, iy, iz, ax, ay, az));
                     ++n_tests;
                 }
                 unsigned long long todo = __ballot(reach);
