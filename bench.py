@@ -279,6 +279,10 @@ def main():
                               "bytes_per_launch": fb_bytes},
             },
         }
+        if F > 1:
+            out["roofline"]["overlap_note"] = (f"{F} frames in flight share the GPU: the event-bracketed kernel time of a "
+                                               "frame includes the time its waves wait behind the other frames', so this "
+                                               "per-kernel fraction understates the kernel; the N=1 line is the clean one")
         quick = ms_per_step < 500.0 and not args.no_extras  # the extras below re-render the frame a few times
         if world == 1 and F == 1 and quick:  # throughput of the same loop with two frames in flight (not `value`)
             c2 = V.Context(local_rank)
