@@ -21,6 +21,9 @@
  *    accumulate, cover scene) DOES NOT EXIST in the reference (SURVEY.md
  *    section 0.1).  It follows the public RTIOW book as recorded in SURVEY.md
  *    section 9; this file is its authority.  PARITY UNPINNED for this mode.
+ *    (What can be checked without the reference is checked analytically:
+ *    tests/furnace.py, a known answer that follows from raytrace06.comp:45-47's
+ *    sky alone, holds for this file and for every GPU kernel.)
  *
  * Arithmetic contract (shared with the HIP kernels, which are written
  * independently of this file): IEEE-754 binary32, round-to-nearest-even,

@@ -211,6 +211,23 @@ def test_device_destination_and_pitch(gpu_ctx, oracle):
     assert (host[:, w:] == 0x7F).all()   # padding untouched
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("case", __import__("furnace").CASES, ids=lambda c: c[0])
+def test_path_blue_furnace_known_answer_on_gpu(gpu_ctx, case, kernel):
+    """The oracle-independent analytic pin of tests/furnace.py, on every PATH kernel."""
+    import furnace
+    name, kind, rho_b, fuzz, ior, expected = case
+    sph, mat = furnace.scene(kind, rho_b, fuzz, ior)
+    w, h = 96, 64
+    cam = V.make_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 60.0, w / h, 0.0, 1.0)
+    gpu_ctx.set_scene(sph, mat)
+    for spp, seed in ((1, 1), (7, 99)):
+        img = gpu_ctx.render(cam, V.make_params(w, h, spp=spp, max_depth=50, seed=seed, kernel=kernel))
+        furnace.check(img, w, h, expected)
+        img = gpu_ctx.render(cam, V.make_params(w, h, spp=spp, max_depth=1, seed=seed, kernel=kernel))
+        furnace.check(img, w, h, 0)     # bounce limit 1: every path that hits returns black
+
+
 def test_frames_in_flight_on_three_contexts(gpu_ctx, oracle):
     """Three contexts with different scenes and cameras render concurrently on their own streams (what
     bench.py does per rank at N > 1, and what the reference's per-swapchain-image command buffers do,

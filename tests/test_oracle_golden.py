@@ -126,3 +126,20 @@ def test_ppm_is_flipped_like_rt_frag(oracle, tmp_path):
     assert data.startswith(b"P6\n2 3\n255\n")
     body = np.frombuffer(data[len(b"P6\n2 3\n255\n"):], np.uint8).reshape(3, 2, 3)
     assert body[0, 0, 0] == 30 and body[2, 0, 0] == 10
+
+
+@pytest.mark.parametrize("case", __import__("furnace").CASES, ids=lambda c: c[0])
+def test_path_blue_furnace_known_answer(oracle, case):
+    """Analytic pin for PATH mode (tests/furnace.py): the blue channel of a single convex sphere under the
+    reference's sky is its blue albedo exactly, for any sampling — checked here on the oracle."""
+    import furnace
+    name, kind, rho_b, fuzz, ior, expected = case
+    sph, mat = furnace.scene(kind, rho_b, fuzz, ior)
+    w, h = 96, 64
+    cam = oracle.make_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 60.0, w / h, 0.0, 1.0)
+    for spp, seed in ((1, 1), (7, 99)):
+        img, _ = oracle.render(sph, mat, cam, V.make_params(w, h, spp=spp, max_depth=50, seed=seed))
+        furnace.check(img, w, h, expected)
+        # bounce limit 1: the one allowed scatter uses it up, every path that hits returns black
+        img, _ = oracle.render(sph, mat, cam, V.make_params(w, h, spp=spp, max_depth=1, seed=seed))
+        furnace.check(img, w, h, 0)
