@@ -48,3 +48,34 @@ def check(img, w, h, expected, vfov_deg=60.0):
     assert (blue[outside] == 255).all(), np.unique(blue[outside])
     # the silhouette itself: a mix of the two, never outside their range
     assert blue.min() >= expected and blue.max() <= 255
+
+
+# Head-on pixel: the camera ray through the middle of the image meets the sphere along its axis.  A
+# mirror sends it straight back, glass lets it straight through (or reflects it straight back): either
+# way the path ends in a horizontal direction, where the sky is lerp(white, (0.5, 0.7, 1.0), 0.5) =
+# (0.75, 0.85, 1.0).  Expected bytes (int)(256 sqrt(albedo * sky)), +-1 for the sub-pixel jitter.
+HEAD_ON = [
+    ("mirror", 1, (0.9, 0.6, 0.5), 0.0, 0.0),
+    ("glass", 2, (1.0, 1.0, 1.0), 0.0, 1.5),
+]
+
+
+def head_on_expected(kind, albedo):
+    sky = (0.75, 0.85, 1.0)
+    att = albedo if kind == 1 else (1.0, 1.0, 1.0)
+    return [min(255, int(256 * math.sqrt(a * s))) for a, s in zip(att, sky)]
+
+
+def head_on_scene(kind, albedo, fuzz, ior):
+    sph = np.zeros(1, V.SPHERE_DTYPE)
+    mat = np.zeros(1, V.MATERIAL_DTYPE)
+    sph[0] = (0.0, 0.0, -1.5, 0.5)
+    mat[0] = (kind, albedo, fuzz, ior, (0, 0))
+    return sph, mat
+
+
+def check_head_on(img, kind, albedo):
+    h, w = img.shape[:2]
+    got = img[h // 2, w // 2, :3].astype(int)
+    want = np.array(head_on_expected(kind, albedo))
+    assert np.abs(got - want).max() <= 1, (got, want)

@@ -228,6 +228,20 @@ def test_path_blue_furnace_known_answer_on_gpu(gpu_ctx, case, kernel):
         furnace.check(img, w, h, 0)     # bounce limit 1: every path that hits returns black
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("case", __import__("furnace").HEAD_ON, ids=lambda c: c[0])
+def test_path_head_on_known_answer_on_gpu(gpu_ctx, case, kernel):
+    """Second analytic pin of tests/furnace.py (mirror / glass sphere seen head-on), on every PATH kernel."""
+    import furnace
+    name, kind, albedo, fuzz, ior = case
+    sph, mat = furnace.head_on_scene(kind, albedo, fuzz, ior)
+    w, h = 513, 385
+    cam = V.make_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 60.0, w / h, 0.0, 1.0)
+    gpu_ctx.set_scene(sph, mat)
+    img = gpu_ctx.render(cam, V.make_params(w, h, spp=4, max_depth=50, seed=5, kernel=kernel))
+    furnace.check_head_on(img, kind, albedo)
+
+
 def test_frames_in_flight_on_three_contexts(gpu_ctx, oracle):
     """Three contexts with different scenes and cameras render concurrently on their own streams (what
     bench.py does per rank at N > 1, and what the reference's per-swapchain-image command buffers do,

@@ -143,3 +143,16 @@ def test_path_blue_furnace_known_answer(oracle, case):
         # bounce limit 1: the one allowed scatter uses it up, every path that hits returns black
         img, _ = oracle.render(sph, mat, cam, V.make_params(w, h, spp=spp, max_depth=1, seed=seed))
         furnace.check(img, w, h, 0)
+
+
+@pytest.mark.parametrize("case", __import__("furnace").HEAD_ON, ids=lambda c: c[0])
+def test_path_head_on_known_answer(oracle, case):
+    """Second analytic pin (tests/furnace.py): the pixel that sees a mirror or glass sphere head-on ends in
+    the horizontal sky whatever happens inside — pins normal, reflect and refract against the sky formula."""
+    import furnace
+    name, kind, albedo, fuzz, ior = case
+    sph, mat = furnace.head_on_scene(kind, albedo, fuzz, ior)
+    w, h = 513, 385
+    cam = oracle.make_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 60.0, w / h, 0.0, 1.0)
+    img, _ = oracle.render(sph, mat, cam, V.make_params(w, h, spp=4, max_depth=50, seed=5))
+    furnace.check_head_on(img, kind, albedo)
