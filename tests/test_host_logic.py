@@ -22,6 +22,30 @@ def test_library_exports_every_declared_symbol():
     assert lib.rtAbiVersion() == 2
 
 
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/rtiow.h compiles as C99 (plain pointers and sizes, no C++), and a C program that references
+    every declared entry point links against librtiow_hip.so — what a cgo / JNI / FFI binding relies on."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    header = open(os.path.join(ROOT, "include", "rtiow.h")).read()
+    names = sorted(set(re.findall(r"\b(rt[A-Z]\w+)\s*\(", header)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "rtiow.h"\n#include <stddef.h>\nint main(void) {\n    void* fns[] = {'
+                   + ", ".join(f"(void*){n}" for n in names) +
+                   '};\n    RtParams p; RtStats s; (void)p; (void)s;\n'
+                   '    return (sizeof(fns) / sizeof(fns[0]) == %d && sizeof(RtUbo5) == 20 && sizeof(RtSphere) == 16 &&\n'
+                   '            sizeof(RtMaterial) == 32 && sizeof(RtCamera) == 88 && sizeof(RtParams) == 56 &&\n'
+                   '            rtAbiVersion() == 2 && rtTileRowCount(10, 4, 0, 2) == 6) ? 0 : 1;\n}\n' % len(names))
+    libdir = os.path.join(ROOT, "vulkan-rtiow_amd")
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-Wno-pedantic",
+                    "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", libdir, "-lrtiow_hip",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0      # host-only entry points: no GPU needed
+
+
 def test_struct_layouts_match_header():
     assert C.sizeof(V.RtUbo5) == 20          # raytrace06.comp:4-10 / main.cpp:109-115
     assert C.sizeof(V.RtSphere) == 16
