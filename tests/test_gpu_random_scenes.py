@@ -28,6 +28,41 @@ def _random_scene(rng, n, scale):
     return sph, mat
 
 
+def fuzz_case(case):
+    """Scene, camera and parameters of case `case` of tools/fuzz_kernels.py (wider than the cases below:
+    up to 6000 spheres, a few very large ones, scales to 3000, cameras from inside to 40 scene radii)."""
+    rng = np.random.default_rng(case)
+    n = int(rng.choice([3, 17, 64, 65, 130, 400, 900, 1600, 2500, 4000, 6000]))
+    scale = float(rng.choice([0.01, 1.0, 1.0, 50.0, 3000.0]))
+    sph, mat = _random_scene(rng, n, scale)
+    if rng.random() < 0.3:   # a few more very large spheres
+        k = min(int(rng.integers(1, 6)), n - 1)
+        if k > 0:
+            sph["radius"][1:1 + k] = rng.uniform(5, 60, k) * scale
+    w, h = int(rng.integers(16, 160)), int(rng.integers(9, 100))
+    dist = float(rng.choice([0.3, 1.0, 2.0, 4.0, 8.0, 40.0])) * scale
+    frm = rng.normal(size=3)
+    frm = frm / np.linalg.norm(frm) * dist + np.array([0, 0.5 * scale * rng.random(), 0])
+    cam = V.make_camera(tuple(frm), (0.0, 0.0, 0.0), (0, 1, 0), float(rng.uniform(15, 110)), w / h,
+                        float(rng.choice([0.0, 0.02, 0.3])) * scale, max(dist, 1e-3))
+    base = dict(spp=int(rng.integers(1, 9)), max_depth=int(rng.choice([2, 8, 50])), seed=int(rng.integers(0, 2**31)),
+                quantiser=int(rng.integers(0, 2)))
+    return sph, mat, cam, w, h, base
+
+
+@pytest.mark.parametrize("case", [100069])
+def test_fuzz_regressions(gpu_ctx, oracle, case):
+    """Cases tools/fuzz_kernels.py once caught.  100069: scale 3000, camera 24000 away aimed at the origin,
+    where the clustered list's padding slots sit: with r^2 = -1 their discriminant hb^2 - (|o|^2 + 1) came
+    out positive through the rounding of |d|^2 and a padding slot was taken for a hit."""
+    sph, mat, cam, w, h, base = fuzz_case(case)
+    want, segs = oracle.render(sph, mat, cam, V.make_params(w, h, **base))
+    gpu_ctx.set_scene(sph, mat)
+    for kernel in (V.KERNEL_PERSISTENT, V.KERNEL_CLUSTERED):
+        got = gpu_ctx.render(cam, V.make_params(w, h, kernel=kernel, **base))
+        assert int((got != want).any(axis=2).sum()) == 0 and gpu_ctx.stats().segments == segs, (case, kernel)
+
+
 @pytest.mark.parametrize("case", range(20))
 def test_random_scene_all_kernels(gpu_ctx, oracle, case):
     rng = np.random.default_rng(1000 + case)

@@ -661,12 +661,16 @@ DI void examine_keyed(const float4* slots, const uint32_t* idx_map, uint32_t slo
     const float hb = fma_(ocz, dz, fma_(ocy, dy, ocx * dx));
     const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
     const float disc = fma_(hb, hb, -cc);
-    if (__builtin_signbit(disc) || disc != disc) return;  // (padding slots, r^2 = -1, always leave here)
+    if (__builtin_signbit(disc) || disc != disc) return;
     const float sq = __builtin_sqrtf(disc);
     float root = -hb - sq;
     root = root > kTMin ? root : -hb + sq;
     if (!(root > kTMin)) return;
     const uint32_t orig = idx_map[slot];
+    // Padding slots sit at the origin with r^2 = -inf and normally leave at the discriminant.  The index
+    // check is not redundant with a finite r^2: far from the origin a ray aimed at it has hb^2 above
+    // |o|^2 + 1 through the rounding of |d|^2 alone (tools/fuzz_kernels.py case 100069).
+    if (orig == 0xFFFFFFFFu) return;
     const unsigned long long k2 =
         (static_cast<unsigned long long>(__float_as_uint(root)) << 32) | (orig << 16) | slot;
     key = k2 < key ? k2 : key;
