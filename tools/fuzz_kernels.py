@@ -26,6 +26,29 @@ with V.Context(0) as ctx:
         if diff or sf.segments != sc.segments:
             bad += 1
             print(f"MISMATCH case {case}: n={n} {w}x{h} pixels={diff} segs {sf.segments} vs {sc.segments}")
+        if case % 3 == 0:   # the same frame as row tiles and as two accumulated dispatches, default kernel choice
+            rng = np.random.default_rng(case + 7)
+            count, block = int(rng.choice([2, 3, 5])), int(rng.choice([1, 3, 4, 16]))
+            tiled = np.zeros_like(flat)
+            for r in range(count):
+                nrows = V.tile_row_count(h, block, r, count)
+                rows = [V.tile_global_row(k, block, r, count) for k in range(nrows)]
+                if len(rows) == 0:
+                    continue
+                part = ctx.render(cam, V.make_params(w, h, row_block=block, tile_rank=r, tile_count=count, **base))
+                tiled[rows] = part
+            if (tiled != flat).any():
+                bad += 1
+                print(f"MISMATCH (tiles {count}x{block}) case {case}")
+            if base["spp"] >= 2:
+                a_spp = base["spp"] // 2
+                b1 = dict(base); b1["spp"] = a_spp
+                b2 = dict(base); b2["spp"] = base["spp"] - a_spp
+                ctx.render(cam, V.make_params(w, h, accumulate=1, sample_offset=0, **b1))
+                acc = ctx.render(cam, V.make_params(w, h, accumulate=1, sample_offset=a_spp, **b2))
+                if (acc != flat).any():
+                    bad += 1
+                    print(f"MISMATCH (accumulate {a_spp}+{base['spp'] - a_spp}) case {case}")
         if (case - first) % 25 == 0:
             print(f"case {case}: n={n} kernel={k} tests/seg flat {sf.sphere_tests / max(1, sf.segments):.0f} "
                   f"clustered {sc.sphere_tests / max(1, sc.segments):.1f}  ({time.time() - t0:.0f} s)", flush=True)
