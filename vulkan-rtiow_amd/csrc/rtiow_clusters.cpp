@@ -106,8 +106,8 @@ void build_clusters(const RtSphere* sph, uint32_t n, double range_diags, Cluster
         todo.push_back({rg.lo + left, rg.hi});
     }
 
-    // padding: r^2 = -inf makes the discriminant -inf for every ray (a finite value would not: far from the
-    // origin, hb^2 - |o|^2 can exceed it through rounding alone); the kernel also checks the slot's index
+    // padding: r^2 = -inf makes the discriminant -inf (or NaN) for every ray, so a padding slot is never a
+    // candidate; a finite value would not do (far from the origin, hb^2 - |o|^2 exceeds it through rounding alone)
     const ClusterF4 never{0.0f, 0.0f, 0.0f, -INFINITY};
     // the large spheres: one group of slots, padded to whole clusters (the sparse trace scans all slots)
     out.n_large_slots = static_cast<uint32_t>((large.size() + kClusterSize - 1u) / kClusterSize * kClusterSize);

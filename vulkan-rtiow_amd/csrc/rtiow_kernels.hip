@@ -666,11 +666,10 @@ DI void examine_keyed(const float4* slots, const uint32_t* idx_map, uint32_t slo
     float root = -hb - sq;
     root = root > kTMin ? root : -hb + sq;
     if (!(root > kTMin)) return;
+    // (Padding slots never get here: their r^2 is -inf, so cc = +inf and the discriminant is -inf or NaN
+    // for every ray.  A finite r^2 would not do: with r^2 = -1, far from the origin a ray aimed at it has
+    // hb^2 above |o|^2 + 1 through the rounding of |d|^2 alone -- tools/fuzz_kernels.py case 100069.)
     const uint32_t orig = idx_map[slot];
-    // Padding slots sit at the origin with r^2 = -inf and normally leave at the discriminant.  The index
-    // check is not redundant with a finite r^2: far from the origin a ray aimed at it has hb^2 above
-    // |o|^2 + 1 through the rounding of |d|^2 alone (tools/fuzz_kernels.py case 100069).
-    if (orig == 0xFFFFFFFFu) return;
     const unsigned long long k2 =
         (static_cast<unsigned long long>(__float_as_uint(root)) << 32) | (orig << 16) | slot;
     key = k2 < key ? k2 : key;
