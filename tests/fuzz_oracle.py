@@ -1,9 +1,10 @@
-"""One-off fuzz (GPU + CPU oracle): the cases of tools/fuzz_kernels.py with at most 900 spheres, every GPU
+"""Not collected by pytest; run by hand on a GPU box: python tests/fuzz_oracle.py [cases] [first_seed]
+One-off fuzz (GPU + CPU oracle): the cases of tools/fuzz_kernels.py with at most 900 spheres, every GPU
 kernel against the oracle, byte for byte.  usage: fuzz_oracle.py [cases] [first_seed]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))  # (this file lives in tests/: it uses the oracle)
 import vulkan_rtiow_amd as V
 from test_gpu_random_scenes import fuzz_case
 import oracle_bind

@@ -2,7 +2,7 @@
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))  # (this file lives in tests/: it uses the oracle)
 import vulkan_rtiow_amd as V
 from test_gpu_random_scenes import fuzz_case
 import oracle_bind
