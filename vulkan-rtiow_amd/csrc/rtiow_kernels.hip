@@ -903,6 +903,8 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
     } else {
         // ---- large scenes: super-cluster boxes in lock-step (32 at a time: 256 clusters), then the
         // cluster boxes of the (ray, super-cluster) pairs that pass, one pair per lane, then the members ----
+        static_assert(64u * kSuperSize <= kItemCap, "one round of (ray, super-cluster) items must fit the cluster list");
+        static_assert(32u * kSuperSize <= 512u, "cluster-in-group index must fit the 9 bits above lane and slot");
         const float4* sbounds = bounds + 2u * a.n_clusters;
         uint16_t* sitems = items + kItemCap;
         for (uint32_t s0 = 0; s0 < a.n_super; s0 += 32u) {
@@ -936,7 +938,8 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
                     while (m) {
                         const uint32_t bit = static_cast<uint32_t>(__builtin_clz(m));
                         m &= ~(0x80000000u >> bit);
-                        walk_clusters(slots, idx_map, a, 0xFF000000u, (s0 + bit) * kSuperSize, sl[r].p, key[r], n_tests);
+                        walk_clusters(slots, idx_map, a, 0xFFFFFFFFu << (32u - kSuperSize), (s0 + bit) * kSuperSize, sl[r].p, key[r],
+                                      n_tests);
                     }
                 }
                 continue;
