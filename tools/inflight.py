@@ -9,7 +9,7 @@ w, h, spp = 1200, 800, 100
 sph, mat = V.make_cover_scene(1, 11)
 cam = V.make_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, w / h, 0.1, 10.0)
 for G in (1, 8):
-    for F in (1, 2, 3):
+    for F in (1, 2, 3, 4, 6):
         ctxs = [V.Context(0) for _ in range(F)]
         streams = [torch.cuda.Stream() for _ in range(F)]
         prm = V.make_params(w, h, spp=spp, max_depth=50, seed=1, row_block=4, tile_rank=0, tile_count=G)
