@@ -269,6 +269,95 @@ def test_frames_in_flight_on_three_contexts(gpu_ctx, oracle):
         ctx.close()
 
 
+def test_one_context_two_streams_is_serialised(gpu_ctx, oracle):
+    """A context has one frame in flight: its pixel queues, accumulators and chunk order are its own.  Renders
+    issued back to back on two different streams are ordered on the device (hipStreamWaitEvent on the end of
+    the previous one) instead of sharing the queues: every frame is the oracle's."""
+    torch = pytest.importorskip("torch")
+    w, h = 200, 120
+    sph, mat, cam = _case(oracle, "cover11", w, h)
+    ctx = V.Context(0)
+    ctx.set_scene(sph, mat)
+    prms = [V.make_params(w, h, spp=6, max_depth=50, seed=31), V.make_params(w, h, spp=4, max_depth=50, seed=32)]
+    wants = [oracle.render(sph, mat, cam, p)[0] for p in prms]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    bufs = [torch.zeros((h, w), dtype=torch.int32, device="cuda:0") for _ in range(6)]
+    torch.cuda.synchronize()
+    for k in range(6):   # alternate streams and frames without any host sync in between
+        ctx.render_device(cam, prms[k % 2], bufs[k].data_ptr(), w * 4, streams[k % 2].cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(6):
+        got = bufs[k].cpu().numpy().view(np.uint8).reshape(h, w, 4)
+        assert np.array_equal(got, wants[k % 2]), k
+    ctx.close()
+
+
+@pytest.mark.parametrize("kernel", [V.KERNEL_PERSISTENT, V.KERNEL_CLUSTERED])
+def test_cost_ordered_dequeue_never_changes_the_frame(gpu_ctx, oracle, kernel):
+    """The second and later frames of one shape hand their pixels out in the order of the previous frame's
+    per-chunk cost (rtiow_device.h: chunk_order); a changed size, tile or scene starts over.  Scheduling only:
+    every frame is the oracle's, and so is a frame of another shape in between."""
+    w, h = 257, 131          # ragged last chunk
+    sph, mat, cam = _case(oracle, "cover11", w, h)
+    ctx = V.Context(0)
+    ctx.set_scene(sph, mat)
+    prm = V.make_params(w, h, spp=5, max_depth=50, seed=8, kernel=kernel)
+    want, segs = oracle.render(sph, mat, cam, prm)
+    for _ in range(4):
+        assert np.array_equal(ctx.render(cam, prm), want)
+        assert ctx.stats().segments == segs
+    tile = V.make_params(w, h, spp=5, max_depth=50, seed=8, kernel=kernel, row_block=3, tile_rank=1, tile_count=4)
+    want_t, _ = oracle.render(sph, mat, cam, tile)
+    for _ in range(3):
+        assert np.array_equal(ctx.render(cam, tile), want_t)
+    assert np.array_equal(ctx.render(cam, prm), want)
+    ctx.close()
+
+
+def test_ch_via_rtrender_keeps_the_callers_height(gpu_ctx, oracle):
+    """main.cpp:103-106 computes the image height as float(w)/(float(w)/float(h)) and truncates it: for ~5 % of
+    sizes that is h - 1.  rtRenderUbo is faithful to that; rtRender, whose caller gave an integer height,
+    renders all h rows (the UBO floats are kept for the u/v arithmetic)."""
+    for w, h in ((2, 7), (2, 13), (400, 225)):
+        ubo = oracle.ubo_from_image(w, h)
+        short = oracle.render_ubo(ubo, V.RT_MODE_CH06)
+        got = gpu_ctx.render(None, V.make_params(w, h, mode=V.RT_MODE_CH06))
+        assert got.shape == (h, w, 4)
+        assert np.array_equal(got[:short.shape[0]], short)
+        if short.shape[0] < h:
+            assert got[h - 1, :, :3].max() > 0      # the last row is rendered, not left untouched
+        assert got[..., 3].max() == 0
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_bounce_limit_one_and_zero(gpu_ctx, oracle, kernel):
+    """max_depth 1: every path is one segment (sky or black), identical on all kernels and the oracle.
+    max_depth 0 (a zero-initialised RtParams) is refused rather than left to differ between kernels."""
+    w, h = 90, 60
+    sph, mat, cam = _case(oracle, "cover11", w, h)
+    gpu_ctx.set_scene(sph, mat)
+    prm = V.make_params(w, h, spp=3, max_depth=1, seed=6, kernel=kernel)
+    want, segs = oracle.render(sph, mat, cam, prm)
+    assert np.array_equal(gpu_ctx.render(cam, prm), want)
+    assert gpu_ctx.stats().segments == segs == w * h * 3
+    with pytest.raises(V.RtError) as e:
+        gpu_ctx.render(cam, V.make_params(w, h, spp=3, max_depth=0, seed=6, kernel=kernel))
+    assert e.value.code == V.RT_ERR_INVALID
+
+
+def test_progressive_with_an_empty_tile(gpu_ctx, oracle):
+    """A rank that owns no rows (more tiles than row blocks) still follows the progressive sequence of its
+    peers: its second dispatch is not refused."""
+    w, h = 40, 8
+    sph, mat, cam = _case(oracle, "three", w, h)
+    gpu_ctx.set_scene(sph, mat)
+    for off in (0, 2, 4):
+        prm = V.make_params(w, h, spp=2, max_depth=10, seed=3, row_block=4, tile_rank=5, tile_count=8,
+                            sample_offset=off, accumulate=1)
+        assert V.tile_row_count(h, 4, 5, 8) == 0
+        assert gpu_ctx.render(cam, prm).shape[0] == 0
+
+
 def test_error_behaviour(gpu_ctx, oracle):
     lib = V.load_library()
     fresh = V.Context(0)

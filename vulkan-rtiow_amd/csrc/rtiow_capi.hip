@@ -22,6 +22,8 @@ struct RtContext {
     int num_cus = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_done = nullptr;  // end of everything the last render enqueued (its stream may differ from the next one's)
+    bool have_done = false;
     float4* d_spheres = nullptr;
     rtiow::ShadeRec* d_shade = nullptr;
     float4* d_cslots = nullptr;   // clustered list (rtiow_clusters.cpp)
@@ -40,6 +42,13 @@ struct RtContext {
     size_t frame_bytes = 0;
     unsigned long long* d_accum = nullptr;  // progressive accumulation: 4 x u64 per pixel of the tile
     size_t accum_bytes = 0;
+    // cost-ordered dequeue: per-chunk cost of the last frame of this shape and the chunk order made from it
+    unsigned long long* d_chunk_cost = nullptr;
+    size_t chunk_cost_bytes = 0;
+    uint32_t* d_chunk_order = nullptr;
+    size_t chunk_order_bytes = 0;
+    uint64_t order_key = 0;                 // (size, tile) the order belongs to
+    bool order_valid = false;
     uint64_t accum_key = 0;                 // which frame the accumulators belong to
     uint32_t accum_samples = 0;             // samples accumulated so far
     bool have_timing = false;
@@ -118,6 +127,7 @@ int rtCreate(int device_id, RtContext** out_ctx) {
         (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&ctx->ev_start)) != hipSuccess ||
         (e = hipEventCreate(&ctx->ev_stop)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming)) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), sizeof(rtiow::Counters))) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counters), sizeof(rtiow::Counters))) != hipSuccess) {
         int rc = fail_hip(nullptr, e, "rtCreate");
@@ -143,6 +153,9 @@ int rtDestroy(RtContext* ctx) {
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+    if (ctx->d_chunk_cost) (void)hipFree(ctx->d_chunk_cost);
+    if (ctx->d_chunk_order) (void)hipFree(ctx->d_chunk_order);
+    if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -267,7 +280,23 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
     ctx->stats.bytes_written = uint64_t(rows) * W * 4;
     ctx->stats.n_spheres = is_ch ? 1u : ctx->n_spheres;
     ctx->have_timing = false;
+    // One frame in flight per context: the counters (with the pixel queues' heads), the timing events, the
+    // accumulators and the chunk order are the context's.  A render on another stream than the last one's
+    // waits, on the device, for everything the last one enqueued.
+    if (ctx->have_done && stream != ctx->last_stream) RT_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_done, 0));
     ctx->last_stream = stream;
+    // progressive accumulation: the accumulators belong to one (size, tile) frame; a new frame starts at
+    // sample_offset 0.  (Checked and recorded before the empty-tile return: a rank that owns no rows still
+    // follows the sequence of its peers.)
+    uint64_t accum_key = 0;
+    if (!is_ch && prm->accumulate) {
+        accum_key = (uint64_t(W) << 40) ^ (uint64_t(H) << 20) ^ (uint64_t(rblock) << 12) ^
+                    (uint64_t(prm->tile_rank) << 6) ^ uint64_t(tcount);
+        if (prm->sample_offset != 0u && (accum_key != ctx->accum_key || prm->sample_offset != ctx->accum_samples))
+            return fail(ctx, RT_ERR_STATE, "rtRender: accumulate continues a different frame or sample count");
+        ctx->accum_key = accum_key;
+        ctx->accum_samples = prm->sample_offset + prm->spp;
+    }
     if (rows == 0) return RT_OK;
 
     // the reference's kernels keep no counters: their frame is launch-bound (7 us of kernel), so the
@@ -309,17 +338,10 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         a.sample_offset = prm->accumulate ? prm->sample_offset : 0u;
         a.accum = nullptr;
         if (prm->accumulate) {
-            // the accumulators belong to one (size, tile) frame; a new frame starts at sample_offset 0
-            const uint64_t key = (uint64_t(W) << 40) ^ (uint64_t(H) << 20) ^ (uint64_t(rblock) << 12) ^
-                                 (uint64_t(prm->tile_rank) << 6) ^ uint64_t(tcount);
-            if (prm->sample_offset != 0u && (key != ctx->accum_key || prm->sample_offset != ctx->accum_samples))
-                return fail(ctx, RT_ERR_STATE, "rtRender: accumulate continues a different frame or sample count");
             int rc = ensure_bytes(ctx, reinterpret_cast<void**>(&ctx->d_accum), &ctx->accum_bytes,
                                   size_t(rows) * W * 4 * sizeof(unsigned long long));
             if (rc != RT_OK) return rc;
             a.accum = ctx->d_accum;
-            ctx->accum_key = key;
-            ctx->accum_samples = prm->sample_offset + prm->spp;
         }
         a.inv_wm1 = 1.0f / static_cast<float>(W - 1);
         a.inv_hm1 = 1.0f / static_cast<float>(H - 1);
@@ -362,9 +384,39 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
                 a.crmax2 = ctx->cluster_rmax2;
             }
         }
+        // cost-ordered dequeue (persistent kernels): this frame is dealt in the order the last frame of the
+        // same shape suggests, and leaves its own per-chunk costs for the next one
+#ifdef RTIOW_NO_ORDER  // (tuning only)
+        const bool ordered = false;
+#else
+        const bool ordered = kernel != rtiow::KERNEL_PIXEL && !getenv("RTIOW_DEBUG_NO_ORDER");  // (tuning only)
+#endif
+        const uint32_t n_chunks = rtiow::chunk_count(rows, W);
+        if (ordered) {
+            const uint64_t okey = ((uint64_t(W) << 40) ^ (uint64_t(H) << 20) ^ (uint64_t(rblock) << 12) ^
+                                   (uint64_t(prm->tile_rank) << 6) ^ uint64_t(tcount)) + 1u;
+            const bool fresh = okey != ctx->order_key || ctx->chunk_cost_bytes < size_t(n_chunks) * 8u ||
+                               ctx->chunk_order_bytes < size_t(n_chunks) * 4u;
+            int rc = ensure_bytes(ctx, reinterpret_cast<void**>(&ctx->d_chunk_cost), &ctx->chunk_cost_bytes, size_t(n_chunks) * 8u);
+            if (rc == RT_OK)
+                rc = ensure_bytes(ctx, reinterpret_cast<void**>(&ctx->d_chunk_order), &ctx->chunk_order_bytes, size_t(n_chunks) * 4u);
+            if (rc != RT_OK) return rc;
+            if (fresh) {
+                RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, size_t(n_chunks) * 8u, stream));
+                ctx->order_valid = false;
+                ctx->order_key = okey;
+            }
+            a.chunk_cost = ctx->d_chunk_cost;
+            a.chunk_order = ctx->order_valid ? ctx->d_chunk_order : nullptr;
+        }
         RT_HIP(ctx, rtiow::launch_path(a, kernel, prm->chunk_spp, ctx->num_cus, stream, &ctx->last_kernel));
+        RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream));
+        if (ordered) {
+            RT_HIP(ctx, rtiow::launch_order_chunks(ctx->d_chunk_cost, ctx->d_chunk_order, n_chunks, stream));
+            ctx->order_valid = true;
+        }
     }
-    RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream));
+    if (is_ch) RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream));
     if (!is_ch)
         RT_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(rtiow::Counters),
                                    hipMemcpyDeviceToHost, stream));
@@ -375,6 +427,8 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
                                      rows, hipMemcpyDeviceToHost, stream));
         RT_HIP(ctx, hipStreamSynchronize(stream));
     }
+    RT_HIP(ctx, hipEventRecord(ctx->ev_done, stream));
+    ctx->have_done = true;
     return RT_OK;
 }
 
@@ -384,10 +438,18 @@ int rtRender(RtContext* ctx, const RtCamera* cam, const RtParams* params, void* 
     if (!params) return fail(ctx, RT_ERR_INVALID, "rtRender: params is null");
     if (params->mode == RT_MODE_CH05 || params->mode == RT_MODE_CH06) {
         // the reference's own kernels take their camera from the 5-float UBO
+        // The image extent is the caller's integer size: main.cpp:106 truncates the UBO's float height back to
+        // an integer, and 800/(800/608)-style quotients land just below the integer for ~5 % of sizes, which
+        // would drop the last row.  The UBO floats are kept for the u/v arithmetic only.
         RtUbo5 ubo;
-        if (rtUboFromImage(params->width, params->height, &ubo) != RT_OK)
+        if (rtUboFromImage(params->width, params->height, &ubo) != RT_OK || params->width > 65536u || params->height > 65536u)
             return fail(ctx, RT_ERR_INVALID, "rtRender: bad image size");
-        return rtRenderUbo(ctx, &ubo, params->mode, dst, dst_pitch, dst_is_device, stream);
+        RtParams p{};
+        p.width = params->width;
+        p.height = params->height;
+        p.mode = params->mode;
+        p.spp = 1;
+        return render_common(ctx, true, &ubo, nullptr, &p, dst, dst_pitch, dst_is_device, stream);
     }
     if (params->mode != RT_MODE_PATH) return fail(ctx, RT_ERR_INVALID, "rtRender: unknown mode");
     if (!cam) return fail(ctx, RT_ERR_INVALID, "rtRender: cam is null");
@@ -396,6 +458,8 @@ int rtRender(RtContext* ctx, const RtCamera* cam, const RtParams* params, void* 
         return fail(ctx, RT_ERR_INVALID, "rtRender: PATH mode needs width,height >= 2");
     if (params->spp == 0 || params->spp > 65536)
         return fail(ctx, RT_ERR_INVALID, "rtRender: spp must be 1..65536");
+    if (params->max_depth == 0)  // (a zero-initialised RtParams; the kernels' bounce loops differ on "no bounce at all")
+        return fail(ctx, RT_ERR_INVALID, "rtRender: max_depth must be at least 1");
     if (params->accumulate && (params->sample_offset > 65536u - params->spp))
         return fail(ctx, RT_ERR_INVALID, "rtRender: sample_offset + spp must not exceed 65536");
     if (params->quantiser > RT_QUANT_BOOK) return fail(ctx, RT_ERR_INVALID, "rtRender: unknown quantiser");
@@ -444,6 +508,23 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
         ctx->stats.sphere_tests = ctx->h_counters->tests ? ctx->h_counters->tests
                                                          : ctx->stats.segments * ctx->stats.n_spheres;
         for (int k = 0; k < 8; ++k) ctx->stats.debug[k] = ctx->h_counters->debug[k];
+#ifdef RTIOW_DEBUG_TIMELINE
+        if (getenv("RTIOW_DEBUG_HIST")) {
+            const rtiow::Counters& c = *ctx->h_counters;
+            static const char* names[3] = {"dry   ", "sparse", "done  "};
+            for (int k = 0; k < 3; ++k) {
+                fprintf(stderr, "waves %s (50 us bins):", names[k]);
+                for (int b = 0; b < 64; ++b) fprintf(stderr, " %u", c.tl_hist[k][b]);
+                fprintf(stderr, "\n");
+            }
+            fprintf(stderr, "iterations after dry: max %u, sum %llu\nqueue 0 head at k/8 of its pixels (us):", c.tl_tail_iters_max, c.tl_tail_iters_sum);
+            for (int k = 1; k <= 8; ++k) fprintf(stderr, " %.0f", c.tl_progress[k] * 0.01);
+            fprintf(stderr, "\nfrom the first sparse iteration on: %llu iterations, %.2f us each, %.1f paths each\n", c.tl_sparse_iters_sum,
+                    c.tl_sparse_iters_sum ? c.tl_sparse_ticks_sum * 0.01 / c.tl_sparse_iters_sum : 0.0,
+                    c.tl_sparse_iters_sum ? double(c.tl_sparse_paths_sum) / c.tl_sparse_iters_sum : 0.0);
+        }
+#endif
+#ifdef RTIOW_DEBUG_COUNTERS
         if (getenv("RTIOW_DEBUG_HIST")) {  // diagnostic builds: when waves ran dry / finished, 0.125 ms bins
             fprintf(stderr, "waves dry :");
             for (int k = 0; k < 32; ++k) fprintf(stderr, " %u", ctx->h_counters->hist_dry[k]);
@@ -459,6 +540,7 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
                         double(c.tail_cyc[0]) / c.tail_iters, double(c.tail_cyc[1]) / c.tail_iters,
                         double(c.tail_cyc[2]) / c.tail_iters);
         }
+#endif
     }
     *out = ctx->stats;
     return RT_OK;

@@ -29,6 +29,13 @@ struct Counters {
     unsigned long long tail_iters, tail_ticks;  // diagnostic builds: iterations / 100 MHz ticks of all waves after running dry
     unsigned long long tail_sparse_iters, tail_sparse_ticks, tail_sparse_paths;  // the sparse ones among them
     unsigned long long tail_cyc[3];  // diagnostic builds: shader cycles of the tail iterations in refill / trace / shade
+    // -DRTIOW_DEBUG_TIMELINE builds: waves by the time (50 us bins from the first wave's start) their queue ran dry,
+    // they first took the sparse trace, and they finished; iterations after running dry
+    unsigned int tl_hist[3][64];
+    unsigned int tl_progress[10];   // 100 MHz ticks at which queue 0's head passed k/8 of its pixels
+    unsigned int tl_tail_iters_max, tl_pad;
+    unsigned long long tl_tail_iters_sum;
+    unsigned long long tl_sparse_iters_sum, tl_sparse_paths_sum, tl_sparse_ticks_sum;  // from a wave's first sparse iteration on
 };
 
 // Device-side shading record of one sphere (32 B), built by rtSetScene from RtSphere + RtMaterial.
@@ -75,6 +82,12 @@ struct PathArgs {
     uint32_t* dst;               // local_rows x dst_stride words
     uint32_t dst_stride;         // in 32-bit words
     Counters* counters;
+    // Cost-ordered dequeue (persistent kernels): the tile's pixels are handed out in chunks of 256; position s
+    // of the chunk sequence holds chunk chunk_order[s] (null: s itself).  Every finished pixel adds the segments
+    // its samples took to chunk_cost[its chunk]; order_chunks() sorts the chunks by that for the next frame,
+    // dearest first, so that the long paths of glass-heavy pixels start early and the frame ends on cheap ones.
+    const uint32_t* chunk_order;
+    unsigned long long* chunk_cost;  // null: not collected
 };
 
 struct ChArgs {
@@ -114,6 +127,19 @@ hipError_t launch_ch(const ChArgs& a, hipStream_t stream);
 // `resolved` receives the variant that was launched (KERNEL_DEFAULT resolves to one of the others)
 hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, int num_cus,
                        hipStream_t stream, uint32_t* resolved);
+// Chunks of the persistent kernels' pixel queue.  One chunk = 32 pixels = one 128-byte line of the frame: all its
+// stores come from the XCD whose queue holds it.  Also the unit of the cost order: measured on the cover frame, one
+// eighth of it (tools/ab_bench.py): 256 pixels 1.71 ms, 128: 1.67, 64: 1.69, 32: 1.64 (32 without the order: 1.72);
+// whole frame 10.31-10.40 either way.
+#ifndef RTIOW_CHUNK_PIX
+#define RTIOW_CHUNK_PIX 32
+#endif
+constexpr uint32_t kChunkPixels = RTIOW_CHUNK_PIX;
+inline uint32_t chunk_count(uint32_t local_rows, uint32_t width) {
+    return static_cast<uint32_t>((static_cast<unsigned long long>(local_rows) * width + kChunkPixels - 1u) / kChunkPixels);
+}
+// order[0..n) = the chunks by descending cost (ties in no particular order); cost[] is zeroed for the next frame
+hipError_t launch_order_chunks(unsigned long long* cost, uint32_t* order, uint32_t n_chunks, hipStream_t stream);
 hipError_t launch_arith(uint32_t op, const float* a, const float* b, const float* c, float* out,
                         uint32_t n, hipStream_t stream);
 

@@ -415,22 +415,22 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 //            32 spheres.  (ACCEL: the two-level clustered list instead, see
 //            trace_clustered; the rest of the kernel is shared.)
 //   sparse   path lengths are heavy-tailed (mean 2.8 segments, 0.1 % reach depth 50
-//            inside glass), so once the queue is empty a wave is left with a
-//            handful of long paths, and a lock-step iteration costs the same for
-//            1 live lane as for 128.  With at most kSparseMax live paths the
-//            wave turns the loop inside out: for each live path in turn, the 64
-//            LANES take 64 different spheres per step (conflict-free ds_read_b128),
-//            each lane keeps the closest of its own, and a 6-step wave reduction
-//            on the (root, index) key finds the hit — the same minimum with the
-//            same tie rule, ~20x sooner than a lock-step pass.
-//   merge    ... and before that, the waves of a workgroup pool their leftovers:
-//            a wave that has nothing left to start and at most kDonateMax live
-//            paths parks them in a workgroup-shared LDS area and exits; the last
-//            wave of the group to get there adopts them all (LDS keeps the
-//            donors' pixel accumulators alive and addressable), so the tail of
-//            4-16 waves costs one wave's iterations instead of 4-16.  No wave
-//            waits on another's work: arrival order comes from one returning
-//            ds_add, and the adopter only waits for donors to finish writing.
+//            inside glass; seen from the slots, where a path counts for as long as it
+//            lives, one slot in fifty holds such a path), so once the queue is empty
+//            EVERY wave is left with a handful of long paths, and a lock-step iteration
+//            costs the same for 1 live lane as for 128.  What then sets the end of the
+//            frame is the latency of one iteration, forty to fifty times over.  With few
+//            live paths the wave turns the loop inside out.  Flat list (trace_sparse): for
+//            each live path in turn the 64 LANES take 64 different spheres per step and a
+//            6-step wave reduction on the (root, index) key finds the hit.  Clustered list
+//            (trace_sparse_parallel): all live paths at once, the lanes sharing out the
+//            (path, box) and (path, member) pairs through LDS work lists; the paths are
+//            first gathered in slot 0, so that shading runs once per iteration, not once
+//            per slot.  Same minimum, same tie rule as the lock-step pass.
+//            (Round 1 also pooled the leftovers of a workgroup's waves in one wave; with the
+//            path-parallel trace that costs more than it saves -- a lone wave's iteration is
+//            no dearer for running beside three others' -- and was removed: cover frame
+//            10.73 -> 10.33 ms, one eighth of it 1.99 -> 1.75 ms.)
 //   shade    miss -> sky radiance, converted to fixed point and added to the
 //            pixel's LDS accumulator (ds_add_u64; integer sums do not depend on
 //            order); hit -> scatter by material (shading records in LDS too
@@ -472,14 +472,10 @@ constexpr uint32_t kBlockSph = 32;  // spheres per candidate word
 #endif
 constexpr uint32_t kSparseMax = RTIOW_SPARSE_MAX; // live paths per wave at or below which the sphere-parallel trace runs
 #ifndef RTIOW_SPARSE_MAX_ACCEL
-#define RTIOW_SPARSE_MAX_ACCEL 10  // measured 6..16: equal within noise; ~1 us per path against ~8 us for a lone dense iteration
+#define RTIOW_SPARSE_MAX_ACCEL 32  // all paths together (trace_sparse_parallel)
 #endif
 constexpr uint32_t kSparseMaxAccel = RTIOW_SPARSE_MAX_ACCEL;  // the same for the clustered list (cluster-parallel trace)
-constexpr uint32_t kDonateMax = 16;  // live paths at or below which a wave parks them in the workgroup's tail pool
-constexpr uint32_t kTailPool = 112; // paths a workgroup's tail pool holds (the adopter keeps <= 16 of its own)
-constexpr uint32_t kTailRecWords = 16;  // 64-byte parked-path records
-constexpr uint32_t kTailBytes = 16u + kTailPool * kTailRecWords * 4u;  // counters + records
-constexpr uint32_t kChunkPix = 256;                  // pixels per XCD-queue chunk (eight 128-byte lines of the frame)
+constexpr uint32_t kChunkPix = kChunkPixels;         // pixels per XCD-queue chunk: 32 = one 128-byte line of the frame
 constexpr uint32_t kAccEntries = 64;                 // pixels a wave may have in flight
 constexpr uint32_t kAccWords = 4;                    // u64 words per entry: r, g, b, samples done
 constexpr uint32_t kWaveAccBytes = kAccEntries * kAccWords * 8u;  // 2 KiB of LDS per wave
@@ -519,6 +515,13 @@ DI void examine_candidate(const float4* lds, uint32_t j, uint32_t n, const Path&
     best_i = static_cast<int>(j);
 }
 
+// -DRTIOW_DEBUG_TIMELINE: three wall-clock stamps per wave (queue dry, first sparse iteration, end) binned into
+// Counters::tl_hist -- cheap enough to leave the kernel's timing as it is (RTIOW_DEBUG_HIST=1 prints them).
+#ifdef RTIOW_DEBUG_TIMELINE
+#define TL_MARK(var) do { if ((var) == 0ull) (var) = wall_clock64(); } while (0)
+#else
+#define TL_MARK(var) ((void)0)
+#endif
 #ifdef RTIOW_DEBUG_COUNTERS
 #define DBG_ADD(var, x) (var) += (x)
 #define DBG_STAMP() __builtin_readcyclecounter()
@@ -1010,102 +1013,205 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
     }
 }
 
-// Minimum over the 64 lanes on the DPP network (row scans, then row 0/2 -> 1/3 and row 1 -> 2-3);
-// the result is read from lane 63.
-template <int CTRL, int ROW_MASK>
-DI uint32_t dpp_min_step(uint32_t x) {  // lanes the DPP pattern leaves without a source keep x
-    const uint32_t o = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(-1, static_cast<int>(x), CTRL, ROW_MASK, 0xf, false));
-    return o < x ? o : x;
-}
-DI uint32_t wave_min_u32(uint32_t v) {
-    v = dpp_min_step<0x111, 0xf>(v);  // row_shr:1
-    v = dpp_min_step<0x112, 0xf>(v);  // row_shr:2
-    v = dpp_min_step<0x114, 0xf>(v);  // row_shr:4
-    v = dpp_min_step<0x118, 0xf>(v);  // row_shr:8
-    v = dpp_min_step<0x142, 0xa>(v);  // row_bcast:15
-    v = dpp_min_step<0x143, 0xc>(v);  // row_bcast:31
-    return __builtin_amdgcn_readlane(v, 63);
+DI uint32_t lane_rank(unsigned long long mask) {  // number of set bits of mask below this lane
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
-// Cluster-parallel closest hit for a wave with few live paths (the end of a frame: what is left are the
-// long paths, one dependent segment after another, so the latency of an iteration is what counts).  One
-// path at a time, its ray in SGPRs: every lane takes one large sphere (exact test) and one cluster box;
-// the boxes the ray reaches come back as a ballot and their members are tested four clusters at a time,
-// one member per lane; the hit is the wave minimum of the packed key.  Same tests, same key, same
-// result as trace_clustered.
-template <int R>
-DI void trace_sparse_clustered(const float4* slots, const uint32_t* idx_map, const float4* bounds, const PathArgs& a,
-                               Slot (&sl)[R], float (&best)[R], int (&best_i)[R], uint32_t (&best_o)[R],
-                               uint32_t& n_tests) {
+// Path-parallel closest hit for a wave with few live paths (at most kSparseParMax): the end of a frame
+// or tile, where what counts is the latency of one iteration of the longest paths.  round 1's cluster-parallel trace
+// took one path at a time (about 1 us each); here the wave's P live paths are worked on together.  Their
+// rays go to LDS and every path gets a group of 64 / P lanes, which strides over the large spheres (exact
+// test) and the top-level boxes (the cluster boxes, or the super-cluster boxes of a large scene) with the
+// path's ray in registers; the boxes a ray reaches are appended to a work list (ballot + mbcnt give the places);
+// super-cluster items are expanded, eight lanes per item, into cluster items; cluster items are consumed
+// sixteen lanes per item, one member per lane.  Every hit is folded into its path's key with ds_min_u64:
+// same tests, same key, same minimum as trace_clustered.  A list that fills up is drained on the spot.
+constexpr uint32_t kSparseParMax = 32;  // paths; their keys and rays fill the wave's 1 KiB result area
+static_assert(kSparseParMax * 8u + kSparseParMax * 24u <= kWaveResultBytes, "keys + rays must fit the result area");
+
+struct SparseRay {
+    float ox, oy, oz, dx, dy, dz;
+};
+DI SparseRay load_sparse_ray(const float* rays, uint32_t p) {
+    const float2* r = reinterpret_cast<const float2*>(rays + p * 6u);  // 24-byte records: three ds_read_b64
+    const float2 a = r[0], b = r[1], c = r[2];
+    return SparseRay{a.x, a.y, b.x, b.y, c.x, c.y};
+}
+
+// consumes `count` (path, cluster) items: sixteen lanes per item, one member each
+DI void sparse_members(const float4* slots, const uint32_t* idx_map, const PathArgs& a, const uint16_t* items,
+                       uint32_t count, const float* rays, unsigned long long* keys, uint32_t& n_tests) {
     const uint32_t lane = threadIdx.x & 63u;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        best[r] = __builtin_inff();
-        best_i[r] = -1;
-        best_o[r] = 0u;
-        unsigned long long live = __ballot(sl[r].active);
-        while (live != 0ull) {
-            const int src = __builtin_ctzll(live);
-            live &= live - 1ull;
-            const Path& p = sl[r].p;
-            const float ox = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.o.x), src));
-            const float oy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.o.y), src));
-            const float oz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.o.z), src));
-            const float dx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.du.x), src));
-            const float dy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.du.y), src));
-            const float dz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(p.du.z), src));
-            unsigned long long key = ~0ull;
-            for (uint32_t j = lane; j < a.n_large; j += 64u) {
-                examine_keyed(slots, idx_map, j, ox, oy, oz, dx, dy, dz, key);
-                ++n_tests;
-            }
-            const float ix = slab_rcp(dx), iy = slab_rcp(dy), iz = slab_rcp(dz);
-            const float ax = -ox * ix, ay = -oy * iy, az = -oz * iz;
-            const float qx = ox - a.ccenter[0], qy = oy - a.ccenter[1], qz = oz - a.ccenter[2];
-            const bool outside = !(fma_(qz, qz, fma_(qy, qy, qx * qx)) <= a.crmax2);
-            for (uint32_t g0 = 0; g0 < a.n_clusters; g0 += 64u) {
-                bool reach = false;
-                if (g0 + lane < a.n_clusters) {
-                    const float4 mid = bounds[2u * (g0 + lane)], half = bounds[2u * (g0 + lane) + 1u];
-                    reach = outside || !__builtin_signbit(slab_gap(mid, half, ix, iy, iz, ax, ay, az));
-                    ++n_tests;
-                }
-                unsigned long long todo = __ballot(reach);
-                while (todo != 0ull) {  // 64 / kClusterSize clusters per pass, one member per lane
-                    constexpr uint32_t kPerPass = 64u / kClusterSize;
-                    const uint32_t q = lane / kClusterSize;
-                    int mine = -1;
-#pragma unroll
-                    for (uint32_t t = 0; t < kPerPass; ++t) {
-                        const int c = todo != 0ull ? __builtin_ctzll(todo) : -1;
-                        todo &= todo - 1ull;   // (0 stays 0)
-                        mine = q == t ? c : mine;
-                    }
-                    if (mine >= 0) {
-                        examine_keyed(slots, idx_map,
-                                      a.n_large_slots + (g0 + static_cast<uint32_t>(mine)) * kClusterStride +
-                                          (lane & (kClusterSize - 1u)),
-                                      ox, oy, oz, dx, dy, dz, key);
-                        ++n_tests;
-                    }
-                }
-            }
-            // wave minimum of the 64-bit key: distances first, then (index, slot) among the nearest
-            const uint32_t hi = static_cast<uint32_t>(key >> 32);
-            const uint32_t hi_min = wave_min_u32(hi);
-            const uint32_t lo_min = wave_min_u32(hi == hi_min ? static_cast<uint32_t>(key) : 0xFFFFFFFFu);
-            if (lane == static_cast<uint32_t>(src) && hi_min != 0xFFFFFFFFu) {
-                best[r] = __uint_as_float(hi_min);
-                best_i[r] = static_cast<int>(lo_min & 0xFFFFu);
-                best_o[r] = lo_min >> 16;
-            }
+    const uint32_t total = count * kClusterSize;
+    for (uint32_t q0 = 0; q0 < total; q0 += 64u) {
+        const uint32_t q = q0 + lane;
+        if (q < total) {
+            const uint32_t item = items[q / kClusterSize];
+            const uint32_t p = item & (kSparseParMax - 1u);
+            const SparseRay ray = load_sparse_ray(rays, p);
+            unsigned long long k2 = ~0ull;
+            examine_keyed(slots, idx_map, a.n_large_slots + (item >> 5) * kClusterStride + (q & (kClusterSize - 1u)),
+                          ray.ox, ray.oy, ray.oz, ray.dx, ray.dy, ray.dz, k2);
+            ++n_tests;
+            if (k2 != ~0ull) atomicMin(&keys[p], k2);
         }
     }
 }
 
-DI uint32_t lane_rank(unsigned long long mask) {  // number of set bits of mask below this lane
-    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
-                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+template <int R>
+DI void trace_sparse_parallel(const float4* slots, const uint32_t* idx_map, const float4* bounds, const PathArgs& a,
+                              uint16_t* items, unsigned long long* results, Slot (&sl)[R], float (&best)[R],
+                              int (&best_i)[R], uint32_t (&best_o)[R], uint32_t& n_tests) {
+    static_assert(kSparseParMax == 32u, "items carry the path in five bits");
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long* keys = results;
+    float* rays = reinterpret_cast<float*>(results + kSparseParMax);
+    uint32_t pidx[R];
+    uint32_t n_live = 0u;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned long long m = __ballot(sl[r].active);
+        pidx[r] = n_live + lane_rank(m);
+        n_live += static_cast<uint32_t>(__popcll(m));
+        if (sl[r].active) {
+            const Path& p = sl[r].p;
+            float2* dst = reinterpret_cast<float2*>(rays + pidx[r] * 6u);
+            dst[0] = make_float2(p.o.x, p.o.y);
+            dst[1] = make_float2(p.o.z, p.du.x);
+            dst[2] = make_float2(p.du.y, p.du.z);
+        }
+    }
+    if (lane < n_live) keys[lane] = ~0ull;
+    // (a wave's LDS operations are performed in order: rays and keys are in place for what follows)
+    const bool two_level = a.n_super != 0u;
+    const float4* top = two_level ? bounds + 2u * a.n_clusters : bounds;
+    const uint32_t n_top = two_level ? a.n_super : a.n_clusters;
+    uint16_t* top_items = two_level ? items + kItemCap : items;
+    uint32_t pending = 0u;   // items in top_items
+    uint32_t pending2 = 0u;  // two_level: cluster items in `items`
+
+    // expands the super-cluster items into cluster items (eight lanes per item), members as the list fills
+    auto expand_supers = [&]() {
+        const uint32_t total = pending * kSuperSize;
+        for (uint32_t q0 = 0; q0 < total; q0 += 64u) {
+            if (pending2 + 64u > kItemCap) {
+                sparse_members(slots, idx_map, a, items, pending2, rays, keys, n_tests);
+                pending2 = 0u;
+            }
+            const uint32_t q = q0 + lane;
+            bool reach = false;
+            uint32_t out_item = 0u;
+            if (q < total) {
+                const uint32_t item = top_items[q / kSuperSize];
+                const uint32_t p = item & (kSparseParMax - 1u);
+                const uint32_t c = (item >> 5) * kSuperSize + (q & (kSuperSize - 1u));
+                const SparseRay ray = load_sparse_ray(rays, p);
+                const float ix = slab_rcp(ray.dx), iy = slab_rcp(ray.dy), iz = slab_rcp(ray.dz);
+                const float qx = ray.ox - a.ccenter[0], qy = ray.oy - a.ccenter[1], qz = ray.oz - a.ccenter[2];
+                const bool outside = !(fma_(qz, qz, fma_(qy, qy, qx * qx)) <= a.crmax2);
+                const float4 mid = bounds[2u * c], half = bounds[2u * c + 1u];
+                reach = outside || !__builtin_signbit(slab_gap(mid, half, ix, iy, iz, -ray.ox * ix, -ray.oy * iy, -ray.oz * iz));
+                ++n_tests;
+                out_item = p | (c << 5);
+            }
+            const unsigned long long m = __ballot(reach);
+            if (reach) items[pending2 + lane_rank(m)] = static_cast<uint16_t>(out_item);
+            pending2 += static_cast<uint32_t>(__popcll(m));
+        }
+        pending = 0u;
+    };
+    auto drain = [&]() {
+        if (two_level) {
+            expand_supers();
+        } else {
+            sparse_members(slots, idx_map, a, items, pending, rays, keys, n_tests);
+            pending = 0u;
+        }
+    };
+
+    // Every path gets a group of 64 / P' consecutive lanes (P' = P rounded up to a power of two): a lane keeps
+    // its path -- ray, reciprocal direction and all -- and strides over the objects of the top level.
+    uint32_t shift = 6u;  // log2 of the group size
+    while ((n_live << shift) > 64u) --shift;
+    const uint32_t gsz = 1u << shift;
+    const uint32_t p = lane >> shift, j0 = lane & (gsz - 1u);
+    const bool mine = p < n_live;
+    const SparseRay ray = load_sparse_ray(rays, mine ? p : 0u);
+    const float ix = slab_rcp(ray.dx), iy = slab_rcp(ray.dy), iz = slab_rcp(ray.dz);
+    const float ax = -ray.ox * ix, ay = -ray.oy * iy, az = -ray.oz * iz;
+    const float qx = ray.ox - a.ccenter[0], qy = ray.oy - a.ccenter[1], qz = ray.oz - a.ccenter[2];
+    const bool outside = !(fma_(qz, qz, fma_(qy, qy, qx * qx)) <= a.crmax2);
+    // the large spheres, exactly
+    for (uint32_t base = 0; base < a.n_large; base += gsz) {
+        const uint32_t j = base + j0;
+        if (mine && j < a.n_large) {
+            unsigned long long k2 = ~0ull;
+            examine_keyed(slots, idx_map, j, ray.ox, ray.oy, ray.oz, ray.dx, ray.dy, ray.dz, k2);
+            ++n_tests;
+            if (k2 != ~0ull) atomicMin(&keys[p], k2);
+        }
+    }
+    // the top-level boxes
+    for (uint32_t base = 0; base < n_top; base += gsz) {
+        if (pending + 64u > kItemCap) drain();
+        const uint32_t b = base + j0;
+        bool reach = false;
+        if (mine && b < n_top) {
+            const float4 mid = top[2u * b], half = top[2u * b + 1u];
+            reach = outside || !__builtin_signbit(slab_gap(mid, half, ix, iy, iz, ax, ay, az));
+            ++n_tests;
+        }
+        const unsigned long long m = __ballot(reach);
+        if (reach) top_items[pending + lane_rank(m)] = static_cast<uint16_t>(p | (b << 5));
+        pending += static_cast<uint32_t>(__popcll(m));
+    }
+    drain();
+    if (two_level) sparse_members(slots, idx_map, a, items, pending2, rays, keys, n_tests);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned long long k = sl[r].active ? keys[pidx[r]] : ~0ull;
+        const bool hit = k != ~0ull;
+        best[r] = hit ? __uint_as_float(static_cast<uint32_t>(k >> 32)) : __builtin_inff();
+        best_i[r] = hit ? static_cast<int>(k & 0xFFFFu) : -1;
+        best_o[r] = static_cast<uint32_t>(k >> 16) & 0xFFFFu;
+    }
+}
+
+// Moves the live paths of slot 1 into idle lanes of slot 0 through a per-wave LDS scratch (64-byte
+// records).  Only for a wave with at most 32 live paths: slot 0 then has room for all of them.
+// Which lane carries a path is immaterial: its pixel's accumulator is addressed by `entry`.
+DI void compact_to_slot0(Slot (&sl)[2], uint32_t* scratch) {
+    const unsigned long long m1 = __ballot(sl[1].active);
+    if (m1 == 0ull) return;
+    const uint32_t n1 = static_cast<uint32_t>(__popcll(m1));
+    const unsigned long long idle0 = __ballot(!sl[0].active);
+    float* recs = reinterpret_cast<float*>(scratch);
+    if (sl[1].active) {
+        Slot& q = sl[1];
+        float* rec = recs + lane_rank(m1) * 16u;
+        rec[0] = q.p.o.x; rec[1] = q.p.o.y; rec[2] = q.p.o.z;
+        rec[3] = q.p.du.x; rec[4] = q.p.du.y; rec[5] = q.p.du.z;
+        rec[6] = q.p.att.x; rec[7] = q.p.att.y; rec[8] = q.p.att.z;
+        rec[9] = __uint_as_float(q.p.rng.state);
+        rec[10] = __uint_as_float(q.depth);
+        rec[11] = __uint_as_float(q.pix);
+        rec[12] = __uint_as_float(q.entry);
+        q.active = false;
+    }
+    const uint32_t k = lane_rank(idle0);
+    if (!sl[0].active && k < n1) {
+        Slot& q = sl[0];
+        const float* rec = recs + k * 16u;
+        q.p.o = mk(rec[0], rec[1], rec[2]);
+        q.p.du = mk(rec[3], rec[4], rec[5]);
+        q.p.att = mk(rec[6], rec[7], rec[8]);
+        q.p.rng = Pcg(__float_as_uint(rec[9]));
+        q.depth = __float_as_uint(rec[10]);
+        q.pix = __float_as_uint(rec[11]);
+        q.entry = __float_as_uint(rec[12]);
+        q.active = true;
+    }
 }
 
 #ifndef RTIOW_ACCEL_MAX_THREADS
@@ -1118,8 +1224,7 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
     // LDS: sphere list [g.n_pad float4] — the flat list, or (ACCEL) the clustered list's slots, then
     // (ACCEL) the slots' original indices [g.n_pad u32] and the boxes [2 (a.n_clusters + a.n_super) float4];
     // then (SHADE_LDS) two float4 of shading record per sphere; then the accumulator entries of every
-    // wave of the workgroup (a wave allocates only from its own 64); then the tail pool:
-    // {parked, arrived, published, pad} + kTailPool records.
+    // wave of the workgroup (a wave allocates only from its own 64).
     extern __shared__ float4 lds_spheres[];
     uint32_t* lds_cidx = reinterpret_cast<uint32_t*>(lds_spheres + g.n_pad);
     float4* lds_cbounds = reinterpret_cast<float4*>(lds_cidx + (ACCEL ? g.n_pad : 0u));
@@ -1127,12 +1232,11 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
     unsigned long long* lds_acc = reinterpret_cast<unsigned long long*>(lds_shade + (SHADE_LDS ? 2u * a.n : 0u));
     const uint32_t waves_in_group = blockDim.x / 64u;
     const uint32_t wave_in_group = threadIdx.x / 64u;
-    uint32_t* lds_tail = reinterpret_cast<uint32_t*>(lds_acc + waves_in_group * (kWaveAccBytes / 8u));
     // (ACCEL) per wave: the phase-2 work list and result keys of trace_clustered
     [[maybe_unused]] unsigned long long* lds_results = reinterpret_cast<unsigned long long*>(
-        reinterpret_cast<unsigned char*>(lds_tail) + kTailBytes + wave_in_group * wave_item_bytes(a.n_super != 0u));
+        reinterpret_cast<unsigned char*>(lds_acc + waves_in_group * (kWaveAccBytes / 8u)) +
+        wave_in_group * wave_item_bytes(a.n_super != 0u));
     [[maybe_unused]] uint16_t* lds_items = reinterpret_cast<uint16_t*>(lds_results + 128);
-    if (threadIdx.x < 4u) lds_tail[threadIdx.x] = 0u;
     if (ACCEL) {
         for (uint32_t i = threadIdx.x; i < g.n_pad; i += blockDim.x) {
             lds_spheres[i] = a.cslots[i];
@@ -1162,13 +1266,16 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
     const uint32_t xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;  // HW_REG_XCC_ID[3:0]
     const uint32_t n_chunks = (g.total_pix + kChunkPix - 1u) / kChunkPix;
     uint32_t cur_pix = 0u, cur_entry = 0u;   // pixel being handed out and its accumulator entry
+    uint32_t cur_seq = ~0u, cur_chunk = 0u;  // position in the chunk sequence the wave is in, and the chunk there
     uint32_t cur_s = a.spp;                  // its next sample; == spp: no pixel open
     unsigned long long free_entries = ~0ull; // accumulator entries not in use
-    bool exhausted = false;                  // the global queue has been drained
-    bool tail_done = false;                  // this wave has been through the workgroup's tail merge
-    // a wave parks at most kDonateMax paths, so that all donors fit the pool
-    const uint32_t donate_max = waves_in_group > 1u ? (kTailPool / (waves_in_group - 1u) < kDonateMax
-                                                            ? kTailPool / (waves_in_group - 1u) : kDonateMax) : 0u;
+    [[maybe_unused]] bool exhausted = false; // the global queue has been drained
+#ifdef RTIOW_DEBUG_TIMELINE
+    const unsigned long long tl_start = wall_clock64();
+    if (lane == 0u) atomicMax(&a.counters->not_t0, ~tl_start);
+    unsigned long long tl_dry = 0ull, tl_sparse = 0ull;
+    uint32_t tl_tail_iters = 0u, tl_sparse_iters = 0u, tl_sparse_paths = 0u;
+#endif
     uint32_t n_paths = 0, n_segments = 0, n_tests = 0;
     [[maybe_unused]] uint32_t dbg_slow_trips = 0, dbg_cands = 0, dbg_iters = 0, dbg_sparse = 0;
     [[maybe_unused]] unsigned long long dbg_t_refill = 0, dbg_t_trace = 0, dbg_t_slow = 0, dbg_t_shade = 0;
@@ -1214,11 +1321,20 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
                                                              __HIP_MEMORY_SCOPE_AGENT);
                             head_now = __builtin_amdgcn_readfirstlane(head_now);
                             if (head_now < vsize) {
-                                uint32_t k = (vsize - head_now) / (g.total_waves / 4u + 1u);  // ~waves per XCD x 2
+#ifndef RTIOW_GUIDE_DIV
+#define RTIOW_GUIDE_DIV 4u
+#endif
+                                uint32_t k = (vsize - head_now) / (g.total_waves / RTIOW_GUIDE_DIV + 1u);  // ~waves per XCD x 2
                                 k = k < 1u ? 1u : (k > g.pool_pix ? g.pool_pix : k);
                                 uint32_t got = 0u;
                                 if (lane == 0u) got = atomicAdd(&a.counters->xcd_head[xq].next, k);
                                 got = __builtin_amdgcn_readfirstlane(got);
+#ifdef RTIOW_DEBUG_TIMELINE
+                                if (xq == 0u && lane == 0u && got < vsize && got * 8u / vsize != (got + k) * 8u / vsize) {
+                                    const unsigned long long t0w = ~__hip_atomic_load(&a.counters->not_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    a.counters->tl_progress[(got + k) * 8u / vsize] = static_cast<unsigned int>(wall_clock64() - t0w);
+                                }
+#endif
                                 if (got < vsize) {
                                     pool_next = got;
                                     pool_end = vsize - got < k ? vsize : got + k;
@@ -1231,6 +1347,7 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
                         }
                         if (!fetched) {
                             exhausted = true;
+                            TL_MARK(tl_dry);
 #ifdef RTIOW_DEBUG_COUNTERS
                             if (!dbg_dry_seen && lane == 0u) {
                                 const unsigned long long t0w = ~__hip_atomic_load(&a.counters->not_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1243,18 +1360,21 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
                             break;
                         }
                     }
-                    {   // virtual index of queue pool_xcd -> pixel of the tile
-                        const uint32_t v = pool_next;
-                        const uint32_t pix = ((v / kChunkPix) * 8u + pool_xcd) * kChunkPix + v % kChunkPix;
-                        if (pix >= g.total_pix) {  // the ragged end of the last chunk
-                            ++pool_next;
-                            continue;
-                        }
+                    // virtual index of queue pool_xcd -> position in the chunk sequence -> chunk -> pixel of the tile
+                    const uint32_t seq = (pool_next / kChunkPix) * 8u + pool_xcd;
+                    if (seq != cur_seq) {  // (wave-uniform: one scalar load per chunk entered)
+                        cur_seq = seq;
+                        cur_chunk = a.chunk_order != nullptr ? __builtin_amdgcn_readfirstlane(a.chunk_order[seq]) : seq;
+                    }
+                    const uint32_t pix = cur_chunk * kChunkPix + pool_next % kChunkPix;
+                    if (pix >= g.total_pix) {  // the ragged end of the last chunk
+                        ++pool_next;
+                        continue;
                     }
                     if (free_entries == 0ull) break;  // 64 pixels in flight: wait for one to finish
                     cur_entry = static_cast<uint32_t>(__builtin_ctzll(free_entries));
                     free_entries &= free_entries - 1ull;
-                    cur_pix = ((pool_next / kChunkPix) * 8u + pool_xcd) * kChunkPix + pool_next % kChunkPix;
+                    cur_pix = pix;
                     ++pool_next;
                     cur_s = 0u;
                     if (lane < kAccWords) lds_acc[(wave_in_group * kAccEntries + cur_entry) * kAccWords + lane] = 0ull;
@@ -1279,83 +1399,12 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
             }
             any_active = any_active || q.active;
         }
-        // ---- tail merge: pool the workgroup's leftovers in one wave ----------------------
-        if (!tail_done && donate_max != 0u && exhausted && cur_s == a.spp) {
-            uint32_t live = 0u;
-#pragma unroll
-            for (int r = 0; r < kSlots; ++r) live += static_cast<uint32_t>(__popcll(__ballot(sl[r].active)));
-            if (live <= donate_max) {
-                tail_done = true;
-                uint32_t order = 0u;
-                if (lane == 0u) order = atomicAdd(&lds_tail[1], 1u);  // returning ds_add: arrival order
-                order = __builtin_amdgcn_readfirstlane(order);
-                float* recs = reinterpret_cast<float*>(lds_tail + 4);
-                if (order + 1u != waves_in_group) {
-                    // donor: park the live paths (records first, then the count they become visible by)
-                    uint32_t base = 0u;
-                    if (lane == 0u && live != 0u) base = atomicAdd(&lds_tail[0], live);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    uint32_t done = 0u;
-#pragma unroll
-                    for (int r = 0; r < kSlots; ++r) {
-                        Slot& q = sl[r];
-                        const unsigned long long m = __ballot(q.active);
-                        if (q.active) {
-                            float* rec = recs + (base + done + lane_rank(m)) * kTailRecWords;
-                            rec[0] = q.p.o.x; rec[1] = q.p.o.y; rec[2] = q.p.o.z;
-                            rec[3] = q.p.du.x; rec[4] = q.p.du.y; rec[5] = q.p.du.z;
-                            rec[6] = q.p.att.x; rec[7] = q.p.att.y; rec[8] = q.p.att.z;
-                            rec[9] = __uint_as_float(q.p.rng.state);
-                            rec[10] = __uint_as_float(q.depth);
-                            rec[11] = __uint_as_float(q.pix);
-                            rec[12] = __uint_as_float(q.entry);
-                            rec[13] = __uint_as_float(1u);  // valid
-                            q.active = false;
-                        }
-                        done += static_cast<uint32_t>(__popcll(m));
-                    }
-                    // published: a wave's LDS operations are performed in order, so the records are
-                    // in place before this tick
-                    if (lane == 0u) atomicAdd(&lds_tail[2], 1u);
-                    break;  // nothing left for this wave; its accumulators live on in LDS
-                }
-                // adopter: every other wave of the group took an earlier arrival tick and is past its
-                // decision; wait (briefly) until each has published, then take everything
-                for (;;) {
-                    uint32_t published = 0u;
-                    if (lane == 0u) published = atomicAdd(&lds_tail[2], 0u);
-                    if (__builtin_amdgcn_readfirstlane(published) + 1u == waves_in_group) break;
-                    __builtin_amdgcn_s_sleep(8);
-                }
-                uint32_t parked = 0u;
-                if (lane == 0u) parked = atomicAdd(&lds_tail[0], 0u);
-                parked = __builtin_amdgcn_readfirstlane(parked);
-                uint32_t taken = 0u;
-#pragma unroll
-                for (int r = 0; r < kSlots; ++r) {
-                    Slot& q = sl[r];
-                    const unsigned long long idle = __ballot(!q.active);
-                    const uint32_t k = taken + lane_rank(idle);
-                    if (!q.active && k < parked) {
-                        const float* rec = recs + k * kTailRecWords;
-                        q.p.o = mk(rec[0], rec[1], rec[2]);
-                        q.p.du = mk(rec[3], rec[4], rec[5]);
-                        q.p.att = mk(rec[6], rec[7], rec[8]);
-                        q.p.rng = Pcg(__float_as_uint(rec[9]));
-                        q.depth = __float_as_uint(rec[10]);
-                        q.pix = __float_as_uint(rec[11]);
-                        q.entry = __float_as_uint(rec[12]);
-                        q.active = true;
-                    }
-                    const uint32_t room = static_cast<uint32_t>(__popcll(idle));
-                    taken += room < parked - taken ? room : parked - taken;
-                    any_active = any_active || q.active;
-                }
-            }
-        }
         // No live path anywhere in the wave: every slot asked and got nothing, so the pool is
         // used up and the global queue drained (an entry shortage needs live paths to exist).
         if (__ballot(any_active) == 0ull) break;
+#ifdef RTIOW_DEBUG_TIMELINE
+        if (tl_dry != 0ull) ++tl_tail_iters;
+#endif
         [[maybe_unused]] const unsigned long long t1 = DBG_STAMP();
 
         // ---- trace ----------------------------------------------------------
@@ -1370,7 +1419,16 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
         const unsigned long long dbg_tr0 = wall_clock64();
 #endif
         if (ACCEL && live_paths <= kSparseMaxAccel) {
-            trace_sparse_clustered<kSlots>(lds_spheres, lds_cidx, lds_cbounds, a, sl, best, best_i, best_o, n_tests);
+            // few paths left: gather them in slot 0 (the shade and refill code below then runs once, not
+            // once per slot), then trace them together
+            compact_to_slot0(sl, reinterpret_cast<uint32_t*>(lds_results));
+            trace_sparse_parallel<kSlots>(lds_spheres, lds_cidx, lds_cbounds, a, lds_items, lds_results, sl, best, best_i,
+                                          best_o, n_tests);
+            TL_MARK(tl_sparse);
+#ifdef RTIOW_DEBUG_TIMELINE
+            ++tl_sparse_iters;
+            tl_sparse_paths += live_paths;
+#endif
             DBG_ADD(dbg_sparse, lane == 0u ? 1u : 0u);
 #ifdef RTIOW_DEBUG_COUNTERS
             if (dbg_dry_seen) {
@@ -1403,6 +1461,7 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
 #pragma unroll
         for (int r = 0; r < kSlots; ++r) {
             Slot& q = sl[r];
+            if (__ballot(q.active) == 0ull) continue;  // (sparse iterations keep their paths in slot 0)
             bool finished = false;
             if (q.active) {
                 ++n_segments;
@@ -1437,12 +1496,16 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
             if (finished) {
                 q.active = false;
                 unsigned long long* acc = lds_acc + q.entry * kAccWords;
-                const unsigned long long before = atomicAdd(acc + 3, 1ull);
-                if (before + 1ull == a.spp) {
+                // low half: samples done; high half: the segments they took (<= 65535 each, <= 65536 samples)
+                const uint32_t segs = q.depth < 0xFFFEu ? q.depth + 1u : 0xFFFFu;
+                const unsigned long long before = atomicAdd(acc + 3, 1ull | (static_cast<unsigned long long>(segs) << 32));
+                if (static_cast<uint32_t>(before) + 1u == a.spp) {
                     completed = true;
                     const uint32_t lr = q.pix / a.width, i = q.pix - lr * a.width;
                     a.dst[static_cast<size_t>(lr) * a.dst_stride + i] =
                         close_pixel(a, q.pix, acc[0], acc[1], acc[2]);
+                    if (a.chunk_cost != nullptr)  // what this pixel cost, for the next frame's chunk order
+                        atomicAdd(a.chunk_cost + q.pix / kChunkPix, (before >> 32) + segs);
                 }
             }
             unsigned long long done_mask = __ballot(completed);
@@ -1465,6 +1528,24 @@ __global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persiste
 #endif
     }
 
+#ifdef RTIOW_DEBUG_TIMELINE
+    if (lane == 0u) {
+        const unsigned long long t0w = ~__hip_atomic_load(&a.counters->not_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long stamps[3] = {tl_dry, tl_sparse, static_cast<unsigned long long>(wall_clock64())};
+        for (int k = 0; k < 3; ++k) {
+            if (stamps[k] == 0ull) continue;
+            const unsigned long long b = (stamps[k] > t0w ? stamps[k] - t0w : 0ull) / 5000ull;  // 50 us bins
+            atomicAdd(&a.counters->tl_hist[k][b > 63ull ? 63ull : b], 1u);
+        }
+        atomicMax(&a.counters->tl_tail_iters_max, tl_tail_iters);
+        atomicAdd(&a.counters->tl_tail_iters_sum, static_cast<unsigned long long>(tl_tail_iters));
+        if (tl_sparse != 0ull) {
+            atomicAdd(&a.counters->tl_sparse_iters_sum, static_cast<unsigned long long>(tl_sparse_iters));
+            atomicAdd(&a.counters->tl_sparse_paths_sum, static_cast<unsigned long long>(tl_sparse_paths));
+            atomicAdd(&a.counters->tl_sparse_ticks_sum, stamps[2] - tl_sparse);
+        }
+    }
+#endif
     // one counter update per wave
     unsigned long long tests64 = n_tests;
     for (int off = 32; off > 0; off >>= 1) {
@@ -1539,7 +1620,56 @@ __global__ void arith_kernel(uint32_t op, const float* a, const float* b, const 
     out[i] = r;
 }
 
+// ============================================================================
+// chunk order for the next frame (cost-ordered dequeue): one workgroup, counting sort on 1024 cost classes
+// ============================================================================
+constexpr uint32_t kOrderBins = 1024;
+__global__ __launch_bounds__(1024) void order_chunks_kernel(unsigned long long* cost, uint32_t* order, uint32_t n) {
+    __shared__ unsigned long long top;
+    __shared__ uint32_t first[kOrderBins];  // histogram, then the first place of each class
+    const uint32_t t = threadIdx.x;
+    if (t == 0u) top = 0ull;
+    first[t] = 0u;
+    __syncthreads();
+    unsigned long long mine = 0ull;
+    for (uint32_t c = t; c < n; c += kOrderBins) mine = cost[c] > mine ? cost[c] : mine;
+    if (mine != 0ull) atomicMax(&top, mine);
+    __syncthreads();
+    const unsigned long long hi = top;
+    // class 0 = dearest; costs are below 2^48 (256 pixels x 2^32), the product below 2^58
+    auto cls = [&](unsigned long long c) {
+        return hi == 0ull ? 0u : (kOrderBins - 1u) - static_cast<uint32_t>(c * (kOrderBins - 1u) / hi);
+    };
+    for (uint32_t c = t; c < n; c += kOrderBins) atomicAdd(&first[cls(cost[c])], 1u);
+    __syncthreads();
+    // exclusive prefix sum over the classes (thread t owns class t): Hillis-Steele in LDS
+    uint32_t incl = first[t];
+    const uint32_t own = incl;
+    for (uint32_t off = 1u; off < kOrderBins; off <<= 1u) {
+        __syncthreads();
+        first[t] = incl;
+        __syncthreads();
+        if (t >= off) incl += first[t - off];
+    }
+    __syncthreads();
+    first[t] = incl - own;
+    __syncthreads();
+    if (hi == 0ull) {  // nothing measured: natural order
+        for (uint32_t c = t; c < n; c += kOrderBins) order[c] = c;
+        return;
+    }
+    for (uint32_t c = t; c < n; c += kOrderBins) {
+        order[atomicAdd(&first[cls(cost[c])], 1u)] = c;
+        cost[c] = 0ull;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_order_chunks(unsigned long long* cost, uint32_t* order, uint32_t n_chunks, hipStream_t stream) {
+    hipLaunchKernelGGL(order_chunks_kernel, dim3(1), dim3(kOrderBins), 0, stream, cost, order, n_chunks);
+    return hipGetLastError();
+}
 
 hipError_t launch_ch(const ChArgs& a, hipStream_t stream) {
     const uint32_t tiles = ((a.width + 15u) / 16u) * ((a.height + 15u) / 16u);
@@ -1573,7 +1703,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // the super-cluster level first (its boxes and second work list), then fall back to the flat list.
     auto clustered_fits = [&](uint32_t n_super) {
         return static_cast<size_t>(a.n_cslots) * 20u + static_cast<size_t>(a.n_clusters + n_super) * 32u +
-                   4u * (kWaveAccBytes + wave_item_bytes(n_super != 0u)) + kTailBytes <= kLdsPerCu;
+                   4u * (kWaveAccBytes + wave_item_bytes(n_super != 0u)) <= kLdsPerCu;
     };
     if (accel && !clustered_fits(a.n_super)) a.n_super = 0u;
     if (accel && !clustered_fits(0u)) accel = false;
@@ -1593,8 +1723,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     g.pool_pix = g.pool_pix < 1u ? 1u : (g.pool_pix > 256u ? 256u : g.pool_pix);
     // LDS per workgroup: the sphere list (16 B per slot; clustered: + 4 B per slot of indices and
     // 32 B per cluster box); while the scene is small, the shading records too (32 B each);
-    // 2 KiB of pixel accumulator entries per wave (clustered: + 3 KiB of work list and result keys) and
-    // the 7 KiB tail pool.
+    // 2 KiB of pixel accumulator entries per wave (clustered: + 2-3 KiB of work lists and result keys).
     const size_t lds_geo = static_cast<size_t>(g.n_pad) * sizeof(float4) +
                            (accel ? static_cast<size_t>(g.n_pad) * 4u + static_cast<size_t>(a.n_clusters + a.n_super) * 32u : 0u);
     const bool shade_lds = lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 28u * 1024u &&
@@ -1616,7 +1745,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     const uint32_t pinned = getenv("RTIOW_DEBUG_THREADS") ? strtoul(getenv("RTIOW_DEBUG_THREADS"), nullptr, 10) : 0u;
     for (uint32_t t = 256u; t <= (accel ? static_cast<uint32_t>(kAccelMaxThreads) : 1024u); t *= 2u) {
         if (pinned != 0u && t != pinned) continue;
-        const size_t need = lds_scene + static_cast<size_t>(t / 64u) * lds_wave + kTailBytes;
+        const size_t need = lds_scene + static_cast<size_t>(t / 64u) * lds_wave;
         if (need > kLdsPerCu) continue;
         int blocks = 0;
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel_fn, static_cast<int>(t), need);
