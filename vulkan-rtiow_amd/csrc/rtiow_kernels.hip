@@ -723,6 +723,9 @@ constexpr uint32_t kItemCap = 512;  // items per list
 constexpr uint32_t kWaveResultBytes = 128u * 8u;  // one u64 key per path slot of the wave
 __host__ __device__ constexpr uint32_t wave_item_bytes(bool two_level) { return kWaveResultBytes + kItemCap * 2u * (two_level ? 2u : 1u); }
 
+// makes the fourth component of a float4 read from LDS count as used, so that the read stays one ds_read_b128
+DI void keep_b128(const float4& v) { asm volatile("" ::"v"(v.w)); }
+
 // slab test of one box (centre, half extent) against a ray given by 1/d, -o/d: sign bit of the result
 // set = the ray leaves the box before it enters it (or before its origin)
 DI float slab_gap(const float4& mid, const float4& half, float ix, float iy, float iz, float ax, float ay, float az) {
@@ -827,25 +830,34 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
     // ---- phase 0: the large spheres, every ray, exact ----
     for (uint32_t base = 0; base < a.n_large; base += 32u) {
         const uint32_t jn = a.n_large - base < 32u ? a.n_large - base : 32u;
+        // four spheres per trip, their reads issued together; the list is padded (to a multiple of
+        // kClusterSize) with slots no ray can hit, whose discriminant is -inf or NaN
+        const uint32_t jn4 = (jn + 3u) & ~3u;
         uint32_t miss[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) miss[r] = 0u;
-#pragma unroll 4
-        for (uint32_t j = 0; j < jn; ++j) {
-            const float4 s = slots[base + j];  // wave-uniform address: LDS broadcast
+        for (uint32_t j = 0; j < jn4; j += 4u) {
+            float4 s4[4];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const Path& p = sl[r].p;
-                const float ocx = p.o.x - s.x, ocy = p.o.y - s.y, ocz = p.o.z - s.z;
-                const float hb = fma_(ocz, p.du.z, fma_(ocy, p.du.y, ocx * p.du.x));
-                const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
-                const float disc = fma_(hb, hb, -cc);
-                miss[r] = __builtin_amdgcn_alignbit(miss[r], __float_as_uint(disc), 31);
+            for (uint32_t u = 0; u < 4u; ++u) s4[u] = slots[base + j + u];  // wave-uniform address: LDS broadcast
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                const float4 s = s4[u];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const Path& p = sl[r].p;
+                    const float ocx = p.o.x - s.x, ocy = p.o.y - s.y, ocz = p.o.z - s.z;
+                    const float hb = fma_(ocz, p.du.z, fma_(ocy, p.du.y, ocx * p.du.x));
+                    const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
+                    const float disc = fma_(hb, hb, -cc);
+                    // (a NaN discriminant may carry either sign: examine_keyed looks again)
+                    miss[r] = __builtin_amdgcn_alignbit(miss[r], __float_as_uint(disc), 31);
+                }
             }
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            uint32_t cand = sl[r].active ? ~miss[r] << (32u - jn) : 0u;  // first sphere of the word at bit 31
+            uint32_t cand = sl[r].active ? ~miss[r] << (32u - jn4) : 0u;  // first sphere of the word at bit 31
             if (sl[r].active) n_tests += jn;
             const Path& p = sl[r].p;
             while (cand) {
@@ -862,13 +874,25 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
 #pragma unroll
             for (int r = 0; r < R; ++r) miss[r] = 0u;
             const uint32_t jn = a.n_clusters - g0 < 32u ? a.n_clusters - g0 : 32u;  // n_clusters is a multiple of 8
-#pragma unroll 4
-            for (uint32_t j = 0; j < jn; ++j) {
-                const float4 mid = bounds[2u * (g0 + j)], half = bounds[2u * (g0 + j) + 1u];  // LDS broadcast
+            // four boxes per trip, their eight ds_read_b128 issued together (one at a time the loop waited out
+            // the LDS latency for every box; and the compiler read the six floats it needs as two ds_read_b96,
+            // which occupy the LDS twice as long as two ds_read_b128 -- hence keep_b128)
+            for (uint32_t j = 0; j < jn; j += 4u) {
+                float4 mid[4], half[4];
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    miss[r] = __builtin_amdgcn_alignbit(
-                        miss[r], __float_as_uint(slab_gap(mid, half, ix[r], iy[r], iz[r], ax[r], ay[r], az[r])), 31);
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    mid[u] = bounds[2u * (g0 + j + u)];
+                    half[u] = bounds[2u * (g0 + j + u) + 1u];  // LDS broadcast
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        miss[r] = __builtin_amdgcn_alignbit(
+                            miss[r], __float_as_uint(slab_gap(mid[u], half[u], ix[r], iy[r], iz[r], ax[r], ay[r], az[r])), 31);
+                    keep_b128(mid[u]);   // (after the use: the asm waits for the read)
+                    keep_b128(half[u]);
+                }
             }
             [[maybe_unused]] const unsigned long long ts0 = DBG_STAMP();
             uint32_t cm[R];
@@ -915,7 +939,25 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
 #pragma unroll
             for (int r = 0; r < R; ++r) miss[r] = 0u;
             const uint32_t jn = a.n_super - s0 < 32u ? a.n_super - s0 : 32u;
-            for (uint32_t j = 0; j < jn; ++j) {
+            uint32_t j = 0;
+            for (; j + 4u <= jn; j += 4u) {  // four boxes per trip, as the cluster boxes above
+                float4 mid[4], half[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    mid[u] = sbounds[2u * (s0 + j + u)];
+                    half[u] = sbounds[2u * (s0 + j + u) + 1u];  // LDS broadcast
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        miss[r] = __builtin_amdgcn_alignbit(
+                            miss[r], __float_as_uint(slab_gap(mid[u], half[u], ix[r], iy[r], iz[r], ax[r], ay[r], az[r])), 31);
+                    keep_b128(mid[u]);
+                    keep_b128(half[u]);
+                }
+            }
+            for (; j < jn; ++j) {
                 const float4 mid = sbounds[2u * (s0 + j)], half = sbounds[2u * (s0 + j) + 1u];  // LDS broadcast
 #pragma unroll
                 for (int r = 0; r < R; ++r)
@@ -1219,8 +1261,12 @@ DI void compact_to_slot0(Slot (&sl)[2], uint32_t* scratch) {
 #endif
 constexpr int kAccelMaxThreads = RTIOW_ACCEL_MAX_THREADS;  // the clustered kernel wants ~166 VGPRs: groups of <= 512
 
+// (Small scenes -- SHADE_LDS -- run three 256-thread groups per CU: three waves per SIMD need <= 168 VGPRs, and the
+// clustered kernel sits right at that edge, so the compiler is told.  Large scenes are held to two waves per SIMD by
+// their LDS footprint and may use more registers.)
 template <bool SHADE_LDS, bool ACCEL>
-__global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) void path_persistent_kernel(PathArgs a, PersistArgs g) {
+__global__ __launch_bounds__(ACCEL ? kAccelMaxThreads : 1024) __attribute__((amdgpu_waves_per_eu(ACCEL && SHADE_LDS ? 3 : 1)))
+void path_persistent_kernel(PathArgs a, PersistArgs g) {
     // LDS: sphere list [g.n_pad float4] — the flat list, or (ACCEL) the clustered list's slots, then
     // (ACCEL) the slots' original indices [g.n_pad u32] and the boxes [2 (a.n_clusters + a.n_super) float4];
     // then (SHADE_LDS) two float4 of shading record per sphere; then the accumulator entries of every
