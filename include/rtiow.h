@@ -11,7 +11,11 @@
  * Conventions (mirroring Vulkan.h:111-133's caller-owned POD handles):
  *   - every function returns an int status (RT_OK == 0) and never aborts
  *     (the reference asserts: Vulkan.cpp:60-62; a C ABI cannot);
- *   - a context belongs to one GPU and one host thread at a time;
+ *   - a context belongs to one GPU and one host thread at a time, and has ONE frame in flight: its
+ *     pixel queues, counters, accumulators and chunk order are its own.  A render on another stream
+ *     than the previous one's is ordered behind it on the device; to overlap frames -- the reference
+ *     keeps one compute fence per swapchain image, RTCHAP06/main.cpp:94-98,313-316 -- use one context
+ *     per frame in flight;
  *   - the framebuffer is W*H packed RGBA8 (bytes R,G,B,A; A == 0 exactly as
  *     imageStore(vec4(color,0.0)) writes it, raytrace06.comp:66), row 0 = the
  *     BOTTOM of the scene (raytrace06.comp:58; the display flips it in
@@ -27,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RTIOW_ABI_VERSION 2
+#define RTIOW_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------ */
 enum {
@@ -113,9 +117,9 @@ typedef struct RtParams {
     uint32_t row_block;
     uint32_t tile_rank;
     uint32_t tile_count;
-    uint32_t kernel;     /* 0 = default (persistent; flat list up to 1024 spheres, clustered beyond);
-                            1 one lane per pixel; 2 persistent, flat list; 3 persistent, clustered
-                            list.  Frames are identical by contract. */
+    uint32_t kernel;     /* 0 = default (persistent waves; flat sphere list below 64 spheres, clustered
+                            list from 64 on); 1 one lane per pixel; 2 persistent, flat list; 3 persistent,
+                            clustered list.  Frames are identical by contract. */
     /* Progressive accumulation, the frame loop of RTCHAP06/main.cpp:304-360 with a running
      * average: with accumulate != 0 this dispatch adds samples sample_offset .. sample_offset+spp-1
      * of every pixel to accumulators the context keeps (reset when sample_offset == 0) and writes
@@ -128,8 +132,11 @@ typedef struct RtParams {
 typedef struct RtStats {
     double kernel_ms;        /* HIP-event time of the device work of the last render      */
     uint64_t paths;          /* camera paths started                                      */
-    uint64_t segments;       /* ray segments traced (each tests every sphere)             */
-    uint64_t sphere_tests;   /* segments * n_spheres                                      */
+    uint64_t segments;       /* ray segments traced                                       */
+    uint64_t sphere_tests;   /* ray-sphere and ray-box tests executed, from the kernel's own counter:
+                                segments * n_spheres for the flat list and the one-lane-per-pixel kernel,
+                                far fewer for the clustered list (large spheres + cluster boxes +
+                                members of the boxes a ray reaches)                         */
     uint64_t bytes_written;  /* algorithmic framebuffer bytes of the last render          */
     uint32_t rows_rendered;
     uint32_t n_spheres;
@@ -157,7 +164,11 @@ int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materi
  *      is enqueued on `stream` (a hipStream_t, NULL = the context's stream)
  *      without a host sync; otherwise dst is host memory and the call returns
  *      when the frame is in it (fixing the unsynchronised compute->graphics
- *      hazard of main.cpp:324 vs :354). */
+ *      hazard of main.cpp:324 vs :354).
+ *      One exception to "enqueues and returns": a camera that has moved beyond 0.95 of the range the
+ *      cluster boxes were inflated for (2 scene diagonals at rtSetScene), or back within an eighth of
+ *      it, has the boxes rebuilt inside this call -- hipDeviceSynchronize, which also drains other
+ *      contexts' frames on the same device, then a re-upload.  Rare (a fly-away camera), never wrong. */
 int rtRender(RtContext* ctx, const RtCamera* cam, const RtParams* params, void* dst,
              size_t dst_pitch, int dst_is_device, void* stream);
 
@@ -182,6 +193,36 @@ int rtGetLastKernel(RtContext* ctx, uint32_t* kernel_out);
  * a single operation.  No reference counterpart. */
 int rtSelfTestArith(RtContext* ctx, uint32_t op, const float* a, const float* b, const float* c,
                     float* out, uint32_t n);
+
+/* ---- several GPUs of one node, one process ---------------------------------------------------
+ * The reference drives exactly one device (RTCHAP06/Vulkan.cpp:87-97; one queue family by assert,
+ * :122); this is the extension BASELINE.json asks for.  device_ids[0] is the root.  Device g renders
+ * the rows r with (r / row_block) % n == g into its own HBM (RtParams.row_block, 0 = 4); the finished
+ * rows are gathered to the root over xGMI (one ncclGather per device in one RCCL group; librccl.so.1 is
+ * opened here, not at library load) and one kernel there puts every row in its place.  The frame is the
+ * single-GPU frame byte for byte.  n == 1 is rtRender itself.  A list that names one device more than
+ * once (a rehearsal of the n-tile path on fewer GPUs) or RTIOW_MULTI_TRANSPORT=peer moves the tiles with
+ * hipMemcpyPeerAsync instead; there is no fallback when RCCL is asked for and fails. */
+typedef struct RtMulti RtMulti;
+int rtCreateMulti(const int* device_ids, int n_devices, RtMulti** out);
+int rtDestroyMulti(RtMulti* m);
+int rtMultiSetScene(RtMulti* m, const RtSphere* spheres, const RtMaterial* materials, uint32_t n_spheres);
+/* dst: height rows of dst_pitch bytes, host memory (the call returns when the frame is in it) or device
+ * memory on the root (enqueued on the root context's stream; rtMultiSynchronize waits).  params->tile_* must
+ * be 0: the tiling is this call's.  RT_MODE_PATH only when n > 1. */
+int rtMultiRender(RtMulti* m, const RtCamera* cam, const RtParams* params, void* dst, size_t dst_pitch,
+                  int dst_is_device);
+int rtMultiSynchronize(RtMulti* m);
+/* Statistics of device number device_index (its tile); *frame_ms (may be NULL) = root-side time from the
+ * first launch to the assembled frame. */
+int rtMultiGetStats(RtMulti* m, int device_index, RtStats* out, double* frame_ms);
+int rtMultiDeviceCount(const RtMulti* m);
+const char* rtMultiTransport(const RtMulti* m); /* "single", "rccl" or "peer-copy" */
+const char* rtMultiGetLastError(const RtMulti* m); /* m may be NULL: errors of rtCreateMulti */
+/* CPU check of the partition / padded gather slots / de-interleave with memcpy standing in for the
+ * communicator: cuts `full` (height x width words) into n_tiles tiles, gathers, reassembles into `out`. */
+int rtMultiSelfTestHost(const uint32_t* full, uint32_t width, uint32_t height, uint32_t row_block,
+                        uint32_t n_tiles, uint32_t* out);
 
 /* ---- host-side helpers (no GPU needed) ---------------------------------- */
 

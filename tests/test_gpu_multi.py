@@ -1,0 +1,104 @@
+"""GPU (-m gpu): the native multi-GPU path behind the C ABI (rtCreateMulti .. rtMultiRender) on the one GPU
+this box has.  N = 1 is the degenerate path; a device list that repeats device 0 runs the whole N-tile path --
+N contexts and streams, block-cyclic tiles, the [N][rows_max][width] gather buffer, the de-interleave kernel --
+with hipMemcpyPeerAsync moving the tiles (RCCL refuses a duplicated device).  The RCCL transport itself needs
+distinct GPUs: it is exercised only by `rtiow_main --gpus N` on a multi-GPU node."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import vulkan_rtiow_amd as V
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MAIN = os.path.join(ROOT, "vulkan-rtiow_amd", "rtiow_main")
+
+
+def _case(oracle, scene, w, h):
+    from golden.make_golden import build_case
+    return build_case(V, oracle, scene, w, h)
+
+
+def test_multi_n1_is_the_single_gpu_render(gpu_ctx, oracle):
+    w, h = 150, 100
+    sph, mat, cam = _case(oracle, "cover11", w, h)
+    prm = V.make_params(w, h, spp=4, max_depth=50, seed=11)
+    want, segs = oracle.render(sph, mat, cam, prm)
+    with V.MultiContext([0]) as m:
+        assert m.transport == "single"
+        m.set_scene(sph, mat)
+        assert np.array_equal(m.render(cam, prm), want)
+        st, ms = m.stats(0)
+        assert st.segments == segs and ms > 0
+
+
+@pytest.mark.parametrize("n,block", [(2, 4), (4, 4), (8, 4), (3, 1), (5, 16)])
+def test_multi_tiles_gathered_and_deinterleaved_equal_the_oracle(oracle, n, block):
+    """Ragged sizes: tiles of unequal height (padded slots), a width that is not a multiple of 4 (word copies
+    in the de-interleave) and one that is (128-bit copies)."""
+    for w, h in ((121, 83), (200, 64)):
+        sph, mat, cam = _case(oracle, "cover11", w, h)
+        prm = V.make_params(w, h, spp=3, max_depth=20, seed=2, row_block=block)
+        want, segs = oracle.render(sph, mat, cam, V.make_params(w, h, spp=3, max_depth=20, seed=2))
+        with V.MultiContext([0] * n) as m:
+            assert m.transport == "peer-copy"
+            m.set_scene(sph, mat)
+            for _ in range(3):     # frames 2 and 3 are dealt in the cost order of the frame before
+                assert np.array_equal(m.render(cam, prm), want), (n, block, w, h)
+            total = sum(m.stats(g)[0].segments for g in range(n))
+            assert total == segs
+            rows = sum(m.stats(g)[0].rows_rendered for g in range(n))
+            assert rows == h
+
+
+def test_multi_device_destination_back_to_back(oracle):
+    """Frames enqueued back to back into device memory: tile g of frame k+1 must not land in the gather buffer
+    while the root still de-interleaves frame k."""
+    torch = pytest.importorskip("torch")
+    w, h = 240, 160
+    sph, mat, cam = _case(oracle, "cover11", w, h)
+    prms = [V.make_params(w, h, spp=2, max_depth=50, seed=s) for s in (5, 6)]
+    wants = [oracle.render(sph, mat, cam, p)[0] for p in prms]
+    bufs = [torch.zeros((h, w), dtype=torch.int32, device="cuda:0") for _ in range(6)]
+    torch.cuda.synchronize()
+    with V.MultiContext([0, 0, 0, 0]) as m:
+        m.set_scene(sph, mat)
+        for k in range(6):
+            m.render_device(cam, prms[k % 2], bufs[k].data_ptr(), w * 4)
+        m.synchronize()
+        for k in range(6):
+            assert np.array_equal(bufs[k].cpu().numpy().view(np.uint8).reshape(h, w, 4), wants[k % 2]), k
+
+
+def test_multi_rejects_what_it_cannot_do(oracle):
+    sph, mat, cam = _case(oracle, "three", 32, 16)
+    with V.MultiContext([0, 0]) as m:
+        m.set_scene(sph, mat)
+        with pytest.raises(V.RtError) as e:      # the tiling is the call's own
+            m.render(cam, V.make_params(32, 16, spp=1, tile_rank=1, tile_count=2))
+        assert e.value.code == V.RT_ERR_INVALID
+        with pytest.raises(V.RtError) as e:      # the reference's kernels are one 7-us dispatch
+            m.render(cam, V.make_params(32, 16, mode=V.RT_MODE_CH06))
+        assert e.value.code == V.RT_ERR_INVALID
+    with pytest.raises(V.RtError) as e:
+        V.MultiContext([0, 99])
+    assert e.value.code == V.RT_ERR_NO_DEVICE
+
+
+def test_harness_gpus_flag(oracle, tmp_path):
+    """rtiow_main --gpus 1 and --devices 0,0,0 (C++ over the same ABI) write the frame the oracle renders."""
+    w, h = 120, 80
+    sph, mat = V.make_cover_scene(1, 11)
+    cam = oracle.make_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, w / h, 0.1, 10.0)
+    want, _ = oracle.render(sph, mat, cam, V.make_params(w, h, spp=3, max_depth=50, seed=1))
+    for flag, val in (("--gpus", "1"), ("--devices", "0,0,0")):
+        out = str(tmp_path / f"multi_{val.replace(',', '')}.ppm")
+        res = subprocess.run([MAIN, "--scene", "cover", "--width", str(w), "--height", str(h), "--spp", "3", flag, val,
+                              "--frames", "2", "--out", out], check=True, capture_output=True, text=True)
+        assert ("transport single" if flag == "--gpus" else "transport peer-copy") in res.stdout
+        data = open(out, "rb").read()
+        _, dims, _, body = data.split(b"\n", 3)
+        img = np.frombuffer(body, np.uint8).reshape(h, w, 3)
+        assert np.array_equal(img, want[::-1, :, :3])

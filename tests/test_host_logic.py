@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     lib = V.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.rtAbiVersion() == 2
+    assert lib.rtAbiVersion() == 3
 
 
 def test_header_is_plain_c_and_links(tmp_path):
@@ -37,7 +37,7 @@ def test_header_is_plain_c_and_links(tmp_path):
                    '};\n    RtParams p; RtStats s; (void)p; (void)s;\n'
                    '    return (sizeof(fns) / sizeof(fns[0]) == %d && sizeof(RtUbo5) == 20 && sizeof(RtSphere) == 16 &&\n'
                    '            sizeof(RtMaterial) == 32 && sizeof(RtCamera) == 88 && sizeof(RtParams) == 56 &&\n'
-                   '            rtAbiVersion() == 2 && rtTileRowCount(10, 4, 0, 2) == 6) ? 0 : 1;\n}\n' % len(names))
+                   '            rtAbiVersion() == 3 && rtTileRowCount(10, 4, 0, 2) == 6) ? 0 : 1;\n}\n' % len(names))
     libdir = os.path.join(ROOT, "vulkan-rtiow_amd")
     exe = tmp_path / "abi"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-Wno-pedantic",
@@ -160,3 +160,35 @@ def test_error_codes_without_gpu_or_context():
     assert lib.rtUboFromImage(0, 5, C.byref(V.RtUbo5())) == V.RT_ERR_INVALID
     assert lib.rtWritePPM(b"/nonexistent-dir/x.ppm", np.zeros(16, np.uint8).ctypes.data, 2, 2, 8) == V.RT_ERR_IO
     assert lib.rtDestroy(None) == V.RT_OK
+
+
+@pytest.mark.parametrize("h,w", [(800, 1200), (83, 120), (7, 5), (1, 3), (2160, 64)])
+def test_multi_gpu_partition_gather_deinterleave_on_the_host(h, w):
+    """the multi-GPU logic of rtMultiRender without a GPU.  rtMultiSelfTestHost cuts a frame
+    into the N block-cyclic tiles the devices would render (padding rows poisoned), moves them through memcpy
+    standing in for the communicator into the [N][rows_max][width] gather buffer, and puts the rows back with
+    the de-interleave the device kernel mirrors.  The frame must come back unchanged for every N and block,
+    including tiles that own no row and N above the number of row blocks."""
+    rng = np.random.default_rng(h * 131 + w)
+    full = rng.integers(0, 2**32, (h, w), dtype=np.uint64).astype(np.uint32)
+    for n in (1, 2, 3, 4, 8, 13, 64):
+        for block in (0, 1, 4, 16, 1000):
+            out = V.multi_selftest_host(full, block, n)
+            assert np.array_equal(out, full), (n, block)
+            # and the slot size is what dist.py pads its gather to
+            if block:
+                D = __import__("importlib").import_module("vulkan-rtiow_amd.dist")
+                assert D.max_tile_rows(h, block, n) == max(V.tile_row_count(h, block, r, n) for r in range(n))
+
+
+def test_multi_gpu_entry_points_fail_cleanly_without_a_gpu():
+    """No CPU fallback: without a usable device rtCreateMulti reports RT_ERR_NO_DEVICE (on a GPU box the
+    -m gpu tests cover the real thing)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: covered by tests/test_gpu_multi.py")
+    with pytest.raises(V.RtError) as e:
+        V.MultiContext([0, 1])
+    assert e.value.code == V.RT_ERR_NO_DEVICE
+    with pytest.raises(V.RtError):
+        V.MultiContext([])

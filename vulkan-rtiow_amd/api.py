@@ -91,6 +91,16 @@ SIGNATURES = {
     "rtTileGlobalRow": (C.c_uint32, [C.c_uint32] * 4),
     "rtWritePPM": (C.c_int, [C.c_char_p, _VP, C.c_uint32, C.c_uint32, C.c_size_t]),
     "rtWritePNG": (C.c_int, [C.c_char_p, _VP, C.c_uint32, C.c_uint32, C.c_size_t]),
+    "rtCreateMulti": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_VP)]),
+    "rtDestroyMulti": (C.c_int, [_VP]),
+    "rtMultiSetScene": (C.c_int, [_VP, _VP, _VP, C.c_uint32]),
+    "rtMultiRender": (C.c_int, [_VP, C.POINTER(RtCamera), C.POINTER(RtParams), _VP, C.c_size_t, C.c_int]),
+    "rtMultiSynchronize": (C.c_int, [_VP]),
+    "rtMultiGetStats": (C.c_int, [_VP, C.c_int, C.POINTER(RtStats), C.POINTER(C.c_double)]),
+    "rtMultiDeviceCount": (C.c_int, [_VP]),
+    "rtMultiTransport": (C.c_char_p, [_VP]),
+    "rtMultiGetLastError": (C.c_char_p, [_VP]),
+    "rtMultiSelfTestHost": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _VP]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -137,7 +147,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.rtAbiVersion() != 2:
+    if lib.rtAbiVersion() != 3:
         raise ImportError("librtiow_hip.so has an unexpected ABI version")
     if path == LIB_PATH:
         _lib = lib
@@ -311,3 +321,78 @@ class Context:
                                                   c.ctypes.data, out.ctypes.data, a.size),
                "rtSelfTestArith")
         return out
+
+
+class MultiContext:
+    """Several GPUs of one node driven from this process (rtCreateMulti .. rtDestroyMulti): block-cyclic
+    row tiles, one RCCL gather to device_ids[0], de-interleave there.  A list that repeats a device is the
+    one-GPU rehearsal of the N-tile path (tiles moved by hipMemcpyPeerAsync)."""
+
+    def __init__(self, device_ids: Sequence[int]):
+        self._lib = load_library()
+        self._h = _VP()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        code = self._lib.rtCreateMulti(ids, len(device_ids), C.byref(self._h))
+        if code != RT_OK:
+            msg = self._lib.rtMultiGetLastError(None)
+            raise RtError(code, "rtCreateMulti", msg.decode() if msg else "")
+        self.device_ids = list(device_ids)
+
+    def _check(self, code: int, where: str) -> None:
+        if code != RT_OK:
+            msg = self._lib.rtMultiGetLastError(self._h)
+            raise RtError(code, where, msg.decode() if msg else "")
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.rtDestroyMulti(self._h)
+            self._h = _VP()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def transport(self) -> str:
+        return self._lib.rtMultiTransport(self._h).decode()
+
+    def set_scene(self, spheres: np.ndarray, materials: np.ndarray) -> None:
+        spheres = np.ascontiguousarray(spheres, SPHERE_DTYPE)
+        materials = np.ascontiguousarray(materials, MATERIAL_DTYPE)
+        self._check(self._lib.rtMultiSetScene(self._h, spheres.ctypes.data, materials.ctypes.data, len(spheres)),
+                    "rtMultiSetScene")
+
+    def render(self, cam: RtCamera, params: RtParams) -> np.ndarray:
+        """The assembled frame as a host array [height, width, 4] (row 0 = scene bottom)."""
+        out = np.zeros((params.height, params.width, 4), np.uint8)
+        self._check(self._lib.rtMultiRender(self._h, C.byref(cam), C.byref(params), out.ctypes.data,
+                                            params.width * 4, 0), "rtMultiRender")
+        return out
+
+    def render_device(self, cam: RtCamera, params: RtParams, dst_ptr: int, pitch: int) -> None:
+        """Enqueues the frame into device memory on device_ids[0]; synchronize() waits for it."""
+        self._check(self._lib.rtMultiRender(self._h, C.byref(cam), C.byref(params), _VP(dst_ptr), pitch, 1),
+                    "rtMultiRender")
+
+    def synchronize(self) -> None:
+        self._check(self._lib.rtMultiSynchronize(self._h), "rtMultiSynchronize")
+
+    def stats(self, device_index: int = 0) -> Tuple[RtStats, float]:
+        st = RtStats()
+        ms = C.c_double(0.0)
+        self._check(self._lib.rtMultiGetStats(self._h, device_index, C.byref(st), C.byref(ms)), "rtMultiGetStats")
+        return st, float(ms.value)
+
+
+def multi_selftest_host(full: np.ndarray, row_block: int, n_tiles: int) -> np.ndarray:
+    """rtMultiSelfTestHost: cuts `full` ([height, width] uint32) into n_tiles tiles, moves them through the
+    host stand-in for the communicator and reassembles them (no GPU involved)."""
+    lib = load_library()
+    full = np.ascontiguousarray(full, np.uint32)
+    out = np.empty_like(full)
+    code = lib.rtMultiSelfTestHost(full.ctypes.data, full.shape[1], full.shape[0], row_block, n_tiles, out.ctypes.data)
+    if code != RT_OK:
+        raise RtError(code, "rtMultiSelfTestHost", (lib.rtMultiGetLastError(None) or b"").decode())
+    return out

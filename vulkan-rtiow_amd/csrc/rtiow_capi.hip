@@ -17,46 +17,7 @@
 #include "../../include/rtiow.h"
 #include "rtiow_device.h"
 
-struct RtContext {
-    int device = -1;
-    int num_cus = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    hipEvent_t ev_done = nullptr;  // end of everything the last render enqueued (its stream may differ from the next one's)
-    bool have_done = false;
-    float4* d_spheres = nullptr;
-    rtiow::ShadeRec* d_shade = nullptr;
-    float4* d_cslots = nullptr;   // clustered list (rtiow_clusters.cpp)
-    uint32_t* d_cidx = nullptr;
-    float4* d_cbounds = nullptr;
-    uint32_t n_clusters = 0, n_super = 0, n_large = 0, n_large_slots = 0, n_cslots = 0;
-    float cluster_center[3] = {0, 0, 0};
-    float cluster_diag = 0, cluster_rmax2 = 0;
-    uint32_t last_kernel = 0;     // variant the last PATH render launched
-    std::vector<RtSphere> host_spheres;  // kept to re-box the clusters for a camera farther out
-    double cluster_range = 0;     // range_diags the current boxes were built for
-    uint32_t n_spheres = 0;
-    rtiow::Counters* d_counters = nullptr;
-    rtiow::Counters* h_counters = nullptr;  // pinned
-    uint32_t* d_frame = nullptr;            // staging framebuffer for host destinations
-    size_t frame_bytes = 0;
-    unsigned long long* d_accum = nullptr;  // progressive accumulation: 4 x u64 per pixel of the tile
-    size_t accum_bytes = 0;
-    // cost-ordered dequeue: per-chunk cost of the last frame of this shape and the chunk order made from it
-    unsigned long long* d_chunk_cost = nullptr;
-    size_t chunk_cost_bytes = 0;
-    uint32_t* d_chunk_order = nullptr;
-    size_t chunk_order_bytes = 0;
-    uint64_t order_key = 0;                 // (size, tile) the order belongs to
-    bool order_valid = false;
-    uint64_t accum_key = 0;                 // which frame the accumulators belong to
-    uint32_t accum_samples = 0;             // samples accumulated so far
-    bool have_timing = false;
-    bool last_is_ch = false;      // the last render ran a CH05/CH06 kernel (no counters)
-    hipStream_t last_stream = nullptr;
-    RtStats stats{};
-    std::string error;
-};
+#include "rtiow_context.h"
 
 namespace {
 

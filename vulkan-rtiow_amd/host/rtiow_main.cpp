@@ -5,7 +5,11 @@
 //
 //   rtiow_main --scene cover|cover4096|three|ch05|ch06|file [--file scene.txt] [--width W --height H
 //              --spp S --depth D --seed N --kernel K --frames F --progressive 0|1 --out file.ppm|file.png
-//              --device G]
+//              --device G | --gpus N | --devices g0,g1,...]
+//
+// --gpus N renders every frame on devices 0..N-1 of this node from this one process (rtCreateMulti: block-cyclic
+// row tiles, one RCCL gather to device 0, de-interleave there); --devices names them (a repeated device is the
+// one-GPU rehearsal of the N-tile path).  The reference drives one device (RTCHAP06/Vulkan.cpp:87-97,122).
 //
 // --progressive 1 makes the F frames a running average (RtParams.accumulate): frame f adds spp new
 // samples to the picture.  A scene file (parameters instead of the compile-time
@@ -79,6 +83,7 @@ int main(int argc, char** argv) {
     std::string scene = "cover", out = "frame.ppm", file;
     uint32_t width = 1200, height = 800, spp = 100, depth = 50, seed = 1, kernel = 0, frames = 1, progressive = 0;
     int device = 0;
+    std::vector<int> devices;  // --gpus / --devices: the multi-GPU path
     for (int i = 1; i + 1 < argc; i += 2) {
         const std::string k = argv[i];
         const char* v = argv[i + 1];
@@ -94,12 +99,32 @@ int main(int argc, char** argv) {
         else if (k == "--file") file = v;
         else if (k == "--frames") frames = std::strtoul(v, nullptr, 10);
         else if (k == "--device") device = std::atoi(v);
+        else if (k == "--gpus") { devices.clear(); for (int g = 0; g < std::atoi(v); ++g) devices.push_back(g); }
+        else if (k == "--devices") {
+            devices.clear();
+            std::istringstream ls(v);
+            std::string tok;
+            while (std::getline(ls, tok, ',')) devices.push_back(std::atoi(tok.c_str()));
+        }
         else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
 
     RtContext* ctx = nullptr;
-    int rc = rtCreate(device, &ctx);
-    if (rc != RT_OK) return die(nullptr, "rtCreate", rc);
+    RtMulti* multi = nullptr;
+    int rc;
+    if (!devices.empty()) {
+        rc = rtCreateMulti(devices.data(), static_cast<int>(devices.size()), &multi);
+        if (rc != RT_OK) { std::fprintf(stderr, "rtCreateMulti failed (%d): %s\n", rc, rtMultiGetLastError(nullptr)); return 1; }
+        std::printf("%d devices, transport %s\n", rtMultiDeviceCount(multi), rtMultiTransport(multi));
+    } else {
+        rc = rtCreate(device, &ctx);
+        if (rc != RT_OK) return die(nullptr, "rtCreate", rc);
+    }
+    auto die_multi = [&](const char* what, int code) {
+        std::fprintf(stderr, "%s failed (%d): %s\n", what, code, rtMultiGetLastError(multi));
+        rtDestroyMulti(multi);
+        return 1;
+    };
 
     RtParams prm{};
     prm.width = width; prm.height = height; prm.spp = spp; prm.max_depth = depth; prm.seed = seed;
@@ -109,6 +134,7 @@ int main(int argc, char** argv) {
     rtUboFromImage(width, height, &ubo);
     if (scene == "ch05" || scene == "ch06") {
         prm.mode = scene == "ch05" ? RT_MODE_CH05 : RT_MODE_CH06;
+        if (multi && devices.size() > 1) { std::fprintf(stderr, "ch05/ch06 are one 7-us dispatch: use --device\n"); rtDestroyMulti(multi); return 2; }
     } else {
         std::vector<RtSphere> sph(5000);
         std::vector<RtMaterial> mat(5000);
@@ -117,7 +143,7 @@ int main(int argc, char** argv) {
             sph.clear();
             mat.clear();
             bool have_cam = false;
-            if (!load_scene_file(file, float(width) / float(height), sph, mat, cam, have_cam)) { rtDestroy(ctx); return 2; }
+            if (!load_scene_file(file, float(width) / float(height), sph, mat, cam, have_cam)) { rtDestroy(ctx); rtDestroyMulti(multi); return 2; }
             if (!have_cam) rtCameraFromUbo(&ubo, &cam);
             n = static_cast<uint32_t>(sph.size());
             rc = RT_OK;
@@ -130,8 +156,10 @@ int main(int argc, char** argv) {
             const float from[3] = {13, 2, 3}, at[3] = {0, 0, 0}, up[3] = {0, 1, 0};
             rtMakeCamera(from, at, up, 20.0f, float(width) / float(height), 0.1f, 10.0f, &cam);
         }
-        if (rc != RT_OK) return die(ctx, "scene", rc);
-        if ((rc = rtSetScene(ctx, sph.data(), mat.data(), n)) != RT_OK) return die(ctx, "rtSetScene", rc);
+        if (rc != RT_OK) { rtDestroyMulti(multi); return die(ctx, "scene", rc); }
+        if (multi) {
+            if ((rc = rtMultiSetScene(multi, sph.data(), mat.data(), n)) != RT_OK) return die_multi("rtMultiSetScene", rc);
+        } else if ((rc = rtSetScene(ctx, sph.data(), mat.data(), n)) != RT_OK) return die(ctx, "rtSetScene", rc);
         std::printf("scene %s: %u spheres\n", scene.c_str(), n);
     }
 
@@ -142,11 +170,28 @@ int main(int argc, char** argv) {
             prm.accumulate = 1;
             prm.sample_offset = f * spp;
         }
-        rc = rtRender(ctx, &cam, &prm, frame.data(), size_t(width) * 4, 0, nullptr);
-        if (rc != RT_OK) return die(ctx, "rtRender", rc);
-        const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         RtStats st{};
-        rtGetStats(ctx, &st);
+        if (multi) {
+            rc = rtMultiRender(multi, &cam, &prm, frame.data(), size_t(width) * 4, 0);
+            if (rc != RT_OK) return die_multi("rtMultiRender", rc);
+        } else {
+            rc = rtRender(ctx, &cam, &prm, frame.data(), size_t(width) * 4, 0, nullptr);
+            if (rc != RT_OK) return die(ctx, "rtRender", rc);
+        }
+        const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (multi) {  // whole-frame time on the root; segments and tests summed over the devices' tiles
+            double frame_ms = 0.0;
+            RtStats part{};
+            for (int g = 0; g < rtMultiDeviceCount(multi); ++g) {
+                if ((rc = rtMultiGetStats(multi, g, &part, &frame_ms)) != RT_OK) return die_multi("rtMultiGetStats", rc);
+                std::printf("  device %d: tile kernel %.3f ms, %u rows\n", devices[g], part.kernel_ms, part.rows_rendered);
+                st.segments += part.segments;
+                st.sphere_tests += part.sphere_tests;
+            }
+            st.kernel_ms = frame_ms;
+        } else {
+            rtGetStats(ctx, &st);
+        }
         const double nominal = double(width) * height * (prm.mode == RT_MODE_PATH ? double(spp) * depth : 1.0);
         std::printf("frame %u: kernel %.3f ms, wall %.3f ms, %.1f Mray/s nominal, %llu segments, %llu sphere tests\n",
                     f, st.kernel_ms, wall, nominal / (st.kernel_ms * 1e-3) / 1e6,
@@ -155,8 +200,9 @@ int main(int argc, char** argv) {
     const bool png = out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0;
     rc = png ? rtWritePNG(out.c_str(), frame.data(), width, height, size_t(width) * 4)
              : rtWritePPM(out.c_str(), frame.data(), width, height, size_t(width) * 4);
-    if (rc != RT_OK) return die(ctx, png ? "rtWritePNG" : "rtWritePPM", rc);
+    if (rc != RT_OK) { rtDestroyMulti(multi); return die(ctx, png ? "rtWritePNG" : "rtWritePPM", rc); }
     std::printf("wrote %s\n", out.c_str());
     rtDestroy(ctx);
+    rtDestroyMulti(multi);
     return 0;
 }
