@@ -79,3 +79,38 @@ def check_head_on(img, kind, albedo):
     got = img[h // 2, w // 2, :3].astype(int)
     want = np.array(head_on_expected(kind, albedo))
     assert np.abs(got - want).max() <= 1, (got, want)
+
+
+# Blue-white hall: SEVERAL bodies, every one with blue albedo exactly 1 -- lambertian, mirror, solid glass, a hollow
+# glass ball (outer radius 0.5, inner radius -0.4: the negative radius flips the normal) and a
+# lambertian floor.  None of these materials absorbs (fuzz 0), the sky's blue is 1 in every direction, so the blue
+# radiance of EVERY sample is 1 whatever it bounces off and however often, provided it gets out within the
+# bounce limit (400: a path of that length has probability ~0.7^400): the blue byte is 255 in every pixel.
+# Any lost path -- a NaN normal, a ray that escapes through the shell's inner surface the wrong way, total
+# internal reflection handled as absorption, a hit dropped among several spheres -- darkens a pixel.
+def white_hall_scene():
+    # (no two surfaces touch or come within 0.05: at a tangent contact the book's t_min = 0.001 lets a ray that
+    # starts closer than that to the other surface pass through it, into the floor, where it bounces until the limit)
+    rows = [((0.0, -100.56, -1.6), 100.0, V.RT_MAT_LAMBERTIAN, (0.5, 0.6, 1.0), 0.0),
+            ((-1.05, 0.0, -1.8), 0.5, V.RT_MAT_LAMBERTIAN, (0.3, 0.5, 1.0), 0.0),
+            ((0.0, 0.0, -1.6), 0.5, V.RT_MAT_DIELECTRIC, (1.0, 1.0, 1.0), 1.5),      # hollow glass: outer ...
+            ((0.0, 0.0, -1.6), -0.4, V.RT_MAT_DIELECTRIC, (1.0, 1.0, 1.0), 1.5),     # ... and inner surface
+            ((1.05, 0.0, -1.8), 0.5, V.RT_MAT_METAL, (0.8, 0.6, 1.0), 0.0),
+            ((0.45, -0.3, -0.9), 0.2, V.RT_MAT_DIELECTRIC, (1.0, 1.0, 1.0), 1.5)]
+    # gaps: balls (bottom -0.5) to floor (top -0.56); lambertian-shell 0.07; shell-mirror 0.07; small ball to floor 0.06
+    sph = np.zeros(len(rows), V.SPHERE_DTYPE)
+    mat = np.zeros(len(rows), V.MATERIAL_DTYPE)
+    for k, (c, r, kind, alb, ior) in enumerate(rows):
+        sph[k] = (c[0], c[1], c[2], r)
+        mat[k] = (kind, alb, 0.0, ior, (0, 0))
+    return sph, mat
+
+
+WHITE_HALL_DEPTH = 400
+
+
+def check_white_hall(img):
+    blue = img[..., 2]
+    assert (blue == 255).all(), (int((blue != 255).sum()), np.unique(blue)[:8])
+    # (and the other channels are not trivially white: the albedos below 1 show)
+    assert img[..., 0].min() < 200

@@ -3,7 +3,7 @@
 screenshots under /root/reference, which do not exist on the GPU box.
 
  (1) ref_jpeg_stats.json   measurements of the reference's own result fixtures
-                           (RTCHAP05/RTCHAP05/21986.jpg, RT01/RT01/4068.jpg): data derived
+                           (RTCHAP05/RTCHAP05/21986.jpg and 1728.jpg, RT01/RT01/4068.jpg): data derived
                            from images, no reference source text.
  (2) ch_known_answers.json the SURVEY.md section 8(c) known-answer table (derived in the survey
                            session from a separate non-fused float32 numpy restatement).
@@ -39,6 +39,22 @@ def jpeg_stats():
         "top_left": img[0, 0].tolist(), "bottom_left": img[h - 1, 0].tolist(),
         "top_right": img[0, w - 1].tolist(), "bottom_right": img[h - 1, w - 1].tolist(),
         "jpeg_tolerance": 3,
+    }
+    # the older state of the same program: a 1024^2 compute image with viewportHeight = 2 shown in the 800x600
+    # window (the quad of main.cpp:174-179 stretches it), so the sphere is an ellipse: pins the UBO path with a
+    # non-square viewport-to-window mapping
+    img = np.asarray(Image.open(os.path.join(REF, "RTCHAP05/RTCHAP05/1728.jpg")).convert("RGB")).astype(int)
+    red = (img[..., 0] > 200) & (img[..., 1] < 60) & (img[..., 2] < 60)
+    ys, xs = np.nonzero(red)
+    h, w = img.shape[:2]
+    out["RTCHAP05/RTCHAP05/1728.jpg"] = {
+        "size": [w, h], "orientation": "display (row 0 = top of picture)", "compute_image": [1024, 1024],
+        "ubo": [1024.0, 1024.0, 2.0, 2.0, 1.0], "red_rule": "r>200 and g<60 and b<60",
+        "red_count": int(red.sum()),
+        "red_bbox_x": [int(xs.min()), int(xs.max())], "red_bbox_y": [int(ys.min()), int(ys.max())],
+        "top_left": img[0, 0].tolist(), "bottom_left": img[h - 1, 0].tolist(),
+        "top_right": img[0, w - 1].tolist(), "bottom_right": img[h - 1, w - 1].tolist(),
+        "centre": img[h // 2, w // 2].tolist(), "bbox_tolerance": 2, "count_tolerance": 0.005, "jpeg_tolerance": 3,
     }
     img = np.asarray(Image.open(os.path.join(REF, "RT01/RT01/4068.jpg")).convert("RGB")).astype(int)
     h, w = img.shape[:2]

@@ -242,6 +242,48 @@ def test_path_head_on_known_answer_on_gpu(gpu_ctx, case, kernel):
     furnace.check_head_on(img, kind, albedo)
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_path_mirror_hall_known_answer_on_gpu(gpu_ctx, kernel):
+    """Third analytic pin (tests/mirrors.py), no oracle in the loop: reflection chains between two mirror balls
+    and a mirror floor against an independent float64 tracer, on every PATH kernel."""
+    import mirrors
+    w, h = 360, 240
+    sph, mat = mirrors.scene()
+    gpu_ctx.set_scene(sph, mat)
+    img = gpu_ctx.render(mirrors.camera(w, h), V.make_params(w, h, spp=8, max_depth=mirrors.MAX_DEPTH, seed=3, kernel=kernel))
+    mirrors.check(img, w, h)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_path_blue_white_hall_known_answer_on_gpu(gpu_ctx, kernel):
+    """Fourth analytic pin (tests/furnace.py), no oracle in the loop: blue albedo 1 everywhere, hollow glass
+    included -- blue is 255 in every pixel on every PATH kernel."""
+    import furnace
+    w, h = 120, 80
+    sph, mat = furnace.white_hall_scene()
+    cam = V.make_camera((0, 0.3, 0.6), (0, 0, -1.6), (0, 1, 0), 55.0, w / h, 0.0, 1.0)
+    gpu_ctx.set_scene(sph, mat)
+    img = gpu_ctx.render(cam, V.make_params(w, h, spp=16, max_depth=furnace.WHITE_HALL_DEPTH, seed=7, kernel=kernel))
+    furnace.check_white_hall(img)
+
+
+def test_ch05_stretched_reference_jpeg_on_gpu(gpu_ctx):
+    """RTCHAP05/RTCHAP05/1728.jpg straight against the HIP kernel (no oracle): UBO {1024, 1024, 2, 2, 1}, flipped
+    and sampled at the 800x600 window's pixel centres; same bounds as the oracle's test of this fixture."""
+    st = json.load(open(os.path.join(GOLD, "ref_jpeg_stats.json")))["RTCHAP05/RTCHAP05/1728.jpg"]
+    img = gpu_ctx.render_ubo(V.RtUbo5(*st["ubo"]), V.RT_MODE_CH05)[::-1]
+    cw, ch = st["compute_image"]
+    w, h = st["size"]
+    shown = img[((np.arange(h) + 0.5) / h * ch).astype(int)][:, ((np.arange(w) + 0.5) / w * cw).astype(int)]
+    hit = (shown[..., 0] == 255) & (shown[..., 1] == 0)
+    ys, xs = np.nonzero(hit)
+    for got, want in zip((xs.min(), xs.max(), ys.min(), ys.max()), st["red_bbox_x"] + st["red_bbox_y"]):
+        assert abs(int(got) - want) <= st["bbox_tolerance"]
+    assert abs(int(hit.sum()) - st["red_count"]) <= st["count_tolerance"] * st["red_count"]
+    for key, (y, x) in {"top_left": (0, 0), "bottom_right": (h - 1, w - 1), "centre": (h // 2, w // 2)}.items():
+        assert np.abs(shown[y, x, :3].astype(int) - np.array(st[key])).max() <= st["jpeg_tolerance"], key
+
+
 def test_frames_in_flight_on_three_contexts(gpu_ctx, oracle):
     """Three contexts with different scenes and cameras render concurrently on their own streams (what
     bench.py does per rank at N > 1, and what the reference's per-swapchain-image command buffers do,

@@ -57,6 +57,34 @@ def test_ch05_against_reference_jpeg(oracle):
         assert np.abs(img[y, x, :3].astype(int) - np.array(st[key])).max() <= tol, key
 
 
+def test_ch05_against_the_stretched_reference_jpeg(oracle):
+    """RTCHAP05/RTCHAP05/1728.jpg, the reference's third result fixture: an older state of the program with a
+    1024x1024 compute image and UBO {1024, 1024, 2, 2, 1} shown in the 800x600 window, so the sphere is an
+    ellipse.  The oracle's 1024^2 frame, flipped like rt.frag:8 and sampled where the window's pixel centres
+    fall on the stretched quad (main.cpp:174-179), has the JPEG's silhouette: bbox within 2 px (exact here),
+    area within 0.5 % (edge pixels blend under the linear sampler and the JPEG), corner and centre colours
+    within JPEG noise.  Pins the UBO path when viewport and window aspect differ."""
+    st = json.load(open(os.path.join(GOLD, "ref_jpeg_stats.json")))["RTCHAP05/RTCHAP05/1728.jpg"]
+    ubo = V.RtUbo5(*st["ubo"])
+    img = oracle.render_ubo(ubo, V.RT_MODE_CH05)[::-1]          # display rows
+    cw, ch = st["compute_image"]
+    assert img.shape[:2] == (ch, cw)
+    w, h = st["size"]
+    yy = ((np.arange(h) + 0.5) / h * ch).astype(int)
+    xx = ((np.arange(w) + 0.5) / w * cw).astype(int)
+    shown = img[yy][:, xx]
+    hit = (shown[..., 0] == 255) & (shown[..., 1] == 0)
+    ys, xs = np.nonzero(hit)
+    tol = st["bbox_tolerance"]
+    for got, want in zip((xs.min(), xs.max(), ys.min(), ys.max()), st["red_bbox_x"] + st["red_bbox_y"]):
+        assert abs(int(got) - want) <= tol, (got, want)
+    assert abs(int(hit.sum()) - st["red_count"]) <= st["count_tolerance"] * st["red_count"]
+    jt = st["jpeg_tolerance"]
+    for key, (y, x) in {"top_left": (0, 0), "bottom_left": (h - 1, 0), "top_right": (0, w - 1),
+                        "bottom_right": (h - 1, w - 1), "centre": (h // 2, w // 2)}.items():
+        assert np.abs(shown[y, x, :3].astype(int) - np.array(st[key])).max() <= jt, key
+
+
 def test_gradient_against_rt01_jpeg(oracle):
     """RT01/RT01/4068.jpg pins the sky gradient's end colours (800x600 window over a 1024^2
     image with viewport 2x2: top/bottom middle of the picture see unit.y = +-1/sqrt(2))."""
@@ -156,3 +184,24 @@ def test_path_head_on_known_answer(oracle, case):
     cam = oracle.make_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 60.0, w / h, 0.0, 1.0)
     img, _ = oracle.render(sph, mat, cam, V.make_params(w, h, spp=4, max_depth=50, seed=5))
     furnace.check_head_on(img, kind, albedo)
+
+
+def test_path_mirror_hall_known_answer(oracle):
+    """Third analytic pin (tests/mirrors.py): two mirror balls facing each other over a mirror floor, checked
+    against an independent float64 tracer of the deterministic reflection chains (sky, one bounce, ... five)."""
+    import mirrors
+    w, h = 360, 240
+    sph, mat = mirrors.scene()
+    img, _ = oracle.render(sph, mat, mirrors.camera(w, h), V.make_params(w, h, spp=8, max_depth=mirrors.MAX_DEPTH, seed=3))
+    mirrors.check(img, w, h)
+
+
+def test_path_blue_white_hall_known_answer(oracle):
+    """Fourth analytic pin (tests/furnace.py): several non-absorbing bodies with blue albedo 1, hollow glass
+    (negative radius) among them: blue is 255 in every pixel, whatever the paths do."""
+    import furnace
+    w, h = 120, 80
+    sph, mat = furnace.white_hall_scene()
+    cam = oracle.make_camera((0, 0.3, 0.6), (0, 0, -1.6), (0, 1, 0), 55.0, w / h, 0.0, 1.0)
+    img, _ = oracle.render(sph, mat, cam, V.make_params(w, h, spp=16, max_depth=furnace.WHITE_HALL_DEPTH, seed=7))
+    furnace.check_white_hall(img)
