@@ -192,3 +192,19 @@ def test_multi_gpu_entry_points_fail_cleanly_without_a_gpu():
     assert e.value.code == V.RT_ERR_NO_DEVICE
     with pytest.raises(V.RtError):
         V.MultiContext([])
+
+
+def test_host_side_under_sanitizers():
+    """the host side of the product (scene builders, camera, tiling, PPM/PNG writers, the
+    two-level list's build, the scene-file parser fed malformed files) and the oracle, compiled from the product's
+    own sources with -fsanitize=address,undefined and run on the CPU (tests/host_asan/).  GPU AddressSanitizer
+    is not available on this pool."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None or shutil.which("make") is None:
+        pytest.skip("no g++ / make")
+    res = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "host_asan"), "run"], capture_output=True, text=True,
+                         timeout=900)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    assert "all checks held" in res.stdout
+    assert "runtime error" not in res.stderr and "AddressSanitizer" not in res.stderr
