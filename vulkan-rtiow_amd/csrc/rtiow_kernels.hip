@@ -719,6 +719,7 @@ DI float slab_rcp(float d) {  // reciprocal of a direction component kept away f
 
 // Per-wave LDS of the clustered trace: the per-ray result keys, the (ray, cluster) work list of phase 2
 // and, for scenes with super-clusters, the (ray, super-cluster) list before it.
+constexpr uint32_t kLargeLockstep = 8;  // up to this many large spheres take the exact test in lock-step (trace_clustered)
 constexpr uint32_t kItemCap = 512;  // items per list
 constexpr uint32_t kWaveResultBytes = 128u * 8u;  // one u64 key per path slot of the wave
 __host__ __device__ constexpr uint32_t wave_item_bytes(bool two_level) { return kWaveResultBytes + kItemCap * 2u * (two_level ? 2u : 1u); }
@@ -828,7 +829,47 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
         outside[r] = !(fma_(qz, qz, fma_(qy, qy, qx * qx)) <= a.crmax2);
     }
     // ---- phase 0: the large spheres, every ray, exact ----
-    for (uint32_t base = 0; base < a.n_large; base += 32u) {
+    // A few of them (the cover scene has four: the ground and the three big balls): straight through the exact test,
+    // in lock-step, no candidate stage.  Nearly every ray is a candidate for the ground anyway (its line meets the huge
+    // sphere somewhere), so the candidate loop below ran two or three divergent trips of the same arithmetic per slot.
+    // A discriminant that is negative, -0 or NaN gives no hit, as in examine_keyed: the sign test is explicit, and the
+    // square root of a NaN fails both comparisons.
+    const uint32_t n_lock = a.n_large <= kLargeLockstep ? a.n_large : 0u;
+    if (n_lock != 0u) {
+        const uint32_t jn4 = (n_lock + 3u) & ~3u;  // (the list is padded with slots no ray can hit: r^2 = -inf)
+        for (uint32_t j = 0; j < jn4; j += 4u) {
+            float4 s4[4];
+            uint32_t lo4[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                s4[u] = slots[j + u];                        // wave-uniform addresses: LDS broadcast
+                lo4[u] = (idx_map[j + u] << 16) | (j + u);   // low word of the key: original index, slot
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                const float4 s = s4[u];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const Path& p = sl[r].p;
+                    const float ocx = p.o.x - s.x, ocy = p.o.y - s.y, ocz = p.o.z - s.z;
+                    const float hb = fma_(ocz, p.du.z, fma_(ocy, p.du.y, ocx * p.du.x));
+                    const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
+                    const float disc = fma_(hb, hb, -cc);
+                    const float sq = __builtin_sqrtf(disc);
+                    float root = -hb - sq;
+                    root = root > kTMin ? root : -hb + sq;
+                    const bool hit = static_cast<int32_t>(__float_as_uint(disc)) >= 0 && root > kTMin;
+                    const unsigned long long k2 =
+                        hit ? (static_cast<unsigned long long>(__float_as_uint(root)) << 32) | lo4[u] : ~0ull;
+                    key[r] = k2 < key[r] ? k2 : key[r];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (sl[r].active) n_tests += n_lock;
+    }
+    for (uint32_t base = 0; base < a.n_large - n_lock; base += 32u) {
         const uint32_t jn = a.n_large - base < 32u ? a.n_large - base : 32u;
         // four spheres per trip, their reads issued together; the list is padded (to a multiple of
         // kClusterSize) with slots no ray can hit, whose discriminant is -inf or NaN
