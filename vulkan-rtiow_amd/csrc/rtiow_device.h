@@ -82,10 +82,11 @@ struct PathArgs {
     uint32_t* dst;               // local_rows x dst_stride words
     uint32_t dst_stride;         // in 32-bit words
     Counters* counters;
-    // Cost-ordered dequeue (persistent kernels): the tile's pixels are handed out in chunks of 256; position s
-    // of the chunk sequence holds chunk chunk_order[s] (null: s itself).  Every finished pixel adds the segments
-    // its samples took to chunk_cost[its chunk]; order_chunks() sorts the chunks by that for the next frame,
-    // dearest first, so that the long paths of glass-heavy pixels start early and the frame ends on cheap ones.
+    // Cost-ordered dequeue (persistent kernels): the tile's pixels are handed out in chunks of 32; place s of the
+    // chunk sequence holds the chunk chunk_order names for it (null: s itself; layout: launch_order_chunks).  Finished
+    // pixels add the segments their samples took to chunk_cost[their chunk] (a wave that renders a whole chunk sums
+    // in LDS and stores once); order_chunks() sorts the chunks by that for the next frame, dearest first, so that
+    // the long paths of glass-heavy pixels start early and the frame ends on cheap ones.
     const uint32_t* chunk_order;
     unsigned long long* chunk_cost;  // null: not collected
 };
@@ -138,7 +139,9 @@ constexpr uint32_t kChunkPixels = RTIOW_CHUNK_PIX;
 inline uint32_t chunk_count(uint32_t local_rows, uint32_t width) {
     return static_cast<uint32_t>((static_cast<unsigned long long>(local_rows) * width + kChunkPixels - 1u) / kChunkPixels);
 }
-// order[0..n) = the chunks by descending cost (ties in no particular order); cost[] is zeroed for the next frame
+// order = the chunks by descending cost (ties in no particular order), place s of that sequence stored at
+// (s % 8) * ceil(n / 8) + s / 8 (queue by queue: queue s % 8 takes it as its (s / 8)-th chunk); cost[] is zeroed for the
+// next frame
 hipError_t launch_order_chunks(unsigned long long* cost, uint32_t* order, uint32_t n_chunks, hipStream_t stream);
 hipError_t launch_arith(uint32_t op, const float* a, const float* b, const float* c, float* out,
                         uint32_t n, hipStream_t stream);
