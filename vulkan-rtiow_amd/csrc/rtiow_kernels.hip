@@ -1305,6 +1305,11 @@ DI void compact_to_slot0(Slot (&sl)[2], uint32_t* scratch) {
     }
 }
 
+#ifndef RTIOW_SMALL_MAX_THREADS
+// largest group of the small-scene clustered variant.  (Tuning: 1024 = one group of sixteen waves, four per SIMD at 128
+// VGPRs: 84 registers spill to scratch and the cover frame takes 10.6 ms instead of 9.8, as in round 1.)
+#define RTIOW_SMALL_MAX_THREADS 512
+#endif
 #ifndef RTIOW_ACCEL_MAX_THREADS
 #define RTIOW_ACCEL_MAX_THREADS 768
 #endif
@@ -1318,7 +1323,7 @@ constexpr int kAccelMaxThreads = RTIOW_ACCEL_MAX_THREADS;
 // (tests/test_host_logic.py checks the compiler's report) and is left alone: with the attribute the same source
 // schedules differently and the cover frame takes 4 % longer, 9.82 -> 10.25 ms.)
 template <bool SHADE_LDS, bool ACCEL>
-__global__ __launch_bounds__(ACCEL ? (SHADE_LDS ? 512 : kAccelMaxThreads) : 1024) __attribute__((amdgpu_waves_per_eu(ACCEL && !SHADE_LDS ? 3 : 1)))
+__global__ __launch_bounds__(ACCEL ? (SHADE_LDS ? RTIOW_SMALL_MAX_THREADS : kAccelMaxThreads) : 1024) __attribute__((amdgpu_waves_per_eu(ACCEL && !SHADE_LDS ? 3 : 1)))
 void path_persistent_kernel(PathArgs a, PersistArgs g) {
     // LDS: sphere list [g.n_pad float4] — the flat list, or (ACCEL) the clustered list's slots, then
     // (ACCEL) the slots' original indices [g.n_pad u32] and the boxes [2 (a.n_clusters + a.n_super) float4];
@@ -1905,7 +1910,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     const uint32_t pinned = getenv("RTIOW_DEBUG_THREADS") ? strtoul(getenv("RTIOW_DEBUG_THREADS"), nullptr, 10) : 0u;
     // (the small-scene variant of the clustered kernel is compiled for groups of at most 512: with the bound at
     // 768 the same source came out 3 % slower on the cover frame)
-    const uint32_t t_max = accel ? (shade_lds ? 512u : static_cast<uint32_t>(kAccelMaxThreads)) : 1024u;
+    const uint32_t t_max = accel ? (shade_lds ? static_cast<uint32_t>(RTIOW_SMALL_MAX_THREADS) : static_cast<uint32_t>(kAccelMaxThreads)) : 1024u;
     for (uint32_t t = 256u; t <= t_max; t += 256u) {
         if (pinned != 0u && t != pinned) continue;
         const size_t need = lds_scene + static_cast<size_t>(t / 64u) * lds_wave;
