@@ -258,8 +258,7 @@ def main():
         fb_bytes = st.bytes_written
         traffic = None
         if world == 1:  # PMC traffic of this workload + kernel, newest profile first
-            for tpath in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "traffic_*.json")),
-                                key=os.path.getmtime, reverse=True):
+            for tpath in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
                 tj = json.load(open(tpath))
                 if tj.get("workload") == args.workload and tj.get("bench_kernel") == KERNEL_NAMES.get(eff_kernel):
                     traffic = tj.get("hbm_bytes_per_launch")
@@ -270,13 +269,15 @@ def main():
         valu_issue = None
         pmc_name = {2: "path_persistent_kernel<true,false>", 3: "path_persistent_kernel<true,true>"}.get(eff_kernel)
         if world == 1 and pmc_name and args.workload == "cover_1200x800_100spp":
-            for ppath in ("r01_pmc.json", "r01f_pmc.json"):
+            for ppath in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):  # newest round first
                 try:
-                    pj = json.load(open(os.path.join(ROOT, "profiles", ppath)))
+                    pj = json.load(open(ppath))
                     insts = pj[pmc_name]["SQ_INSTS_VALU"]["mean_per_launch"]
                     valu_issue = {"valu_wave_instructions_per_launch": insts,
                                   "rate": insts / (kernel_ms * 1e-3), "peak": VALU_ISSUE_PEAK, "unit": "wave instructions/s",
-                                  "frac": insts / (kernel_ms * 1e-3) / VALU_ISSUE_PEAK, "source": "profiles/" + ppath}
+                                  "frac": insts / (kernel_ms * 1e-3) / VALU_ISSUE_PEAK,
+                                  "lane_occupancy": pj[pmc_name].get("lane_occupancy_valu"),
+                                  "source": "profiles/" + os.path.basename(ppath)}
                     break
                 except (OSError, KeyError, ValueError):
                     continue

@@ -2,7 +2,7 @@
 # Collects the rocprofv3 evidence bench.py's numbers are checked against (run on the GPU box):
 #   1. --kernel-trace --stats        per-kernel durations of the exact bench command
 #   2. --pmc FETCH_SIZE / WRITE_SIZE HBM traffic of each kernel (separate passes: TCC slots)
-#   3. --pmc SQ_*                    VALU / LDS / wait mix of the path kernel
+#   3. --pmc SQ_*                    VALU / LDS / wait mix of the path kernel (+ 4. lane occupancy, 5. ch_kernel)
 # Raw output goes to gpurun_out/prof_<tag>_*/ ; tools/profile_summary.py condenses it into profiles/.
 set -e
 TAG=${1:-r01}
@@ -19,4 +19,9 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_
     --output-format csv -d $O/prof_${TAG}_sq -- $BENCH > $O/prof_${TAG}_sq.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE \
     --output-format csv -d $O/prof_${TAG}_lds -- $BENCH > $O/prof_${TAG}_lds.log 2>&1 || true
+#   4. lane occupancy of the vector instructions: SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU), and the rest of the mix
+rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_INSTS_LDS_ATOMIC \
+    --output-format csv -d $O/prof_${TAG}_lane -- $BENCH > $O/prof_${TAG}_lane.log 2>&1 || true
+#   5. the reference's own kernel at a size where bytes matter: 16384^2 CH06 frames
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_ch -- python3 $R/tools/ch_bandwidth.py > $O/prof_${TAG}_ch.log 2>&1 || true
 cd $R && python3 tools/profile_summary.py $TAG

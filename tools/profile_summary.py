@@ -26,7 +26,7 @@ if os.path.exists(log):
             open(os.path.join(prof, f"{tag}_bench_under_rocprof.json"), "w").write(line)
 
 pmc = {}
-for kind in ("fetch", "write", "sq", "lds"):
+for kind in ("fetch", "write", "sq", "lds", "lane"):
     f = one(f"prof_{tag}_{kind}/**/*_counter_collection.csv")
     if not f:
         continue
@@ -60,6 +60,15 @@ if pk and "FETCH_SIZE" in pmc[pk] and "WRITE_SIZE" in pmc[pk]:
                "resolve_kernel_hbm_bytes_per_launch": bytes_of(rk) if rk and "FETCH_SIZE" in pmc[rk] else None,
                "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reads half of a wide stream)"}
     json.dump(traffic, open(os.path.join(prof, f"traffic_{tag}.json"), "w"), indent=1)
+for k, v in pmc.items():  # derived: share of the 64 lanes active in an average vector instruction
+    if isinstance(v, dict) and "SQ_THREAD_CYCLES_VALU" in v and "SQ_ACTIVE_INST_VALU" in v:
+        v["lane_occupancy_valu"] = v["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"] / (64.0 * max(1.0, v["SQ_ACTIVE_INST_VALU"]["mean_per_launch"]))
 json.dump(pmc, open(os.path.join(prof, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+chs = one(f"prof_{tag}_ch/**/*_kernel_stats.csv")
+if chs:
+    shutil.copy(chs, os.path.join(prof, f"{tag}_ch_kernel_stats.csv"))
+    chlog = os.path.join(out, f"prof_{tag}_ch.log")
+    if os.path.exists(chlog):
+        shutil.copy(chlog, os.path.join(prof, f"{tag}_ch_bandwidth.txt"))
 print("kernel stats:", open(os.path.join(prof, f"{tag}_kernel_stats.csv")).read() if ks else "missing")
 print("traffic:", traffic)

@@ -373,7 +373,7 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         RT_HIP(ctx, rtiow::launch_path(a, kernel, prm->chunk_spp, ctx->num_cus, stream, &ctx->last_kernel));
         RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream));
         if (ordered) {
-            RT_HIP(ctx, rtiow::launch_order_chunks(ctx->d_chunk_cost, ctx->d_chunk_order, n_chunks, stream));
+            RT_HIP(ctx, rtiow::launch_order_chunks(ctx->d_chunk_cost, ctx->d_chunk_order, n_chunks, prm->spp, stream));
             ctx->order_valid = true;
         }
     }

@@ -142,7 +142,7 @@ inline uint32_t chunk_count(uint32_t local_rows, uint32_t width) {
 // order = the chunks by descending cost (ties in no particular order), place s of that sequence stored at
 // (s % 8) * ceil(n / 8) + s / 8 (queue by queue: queue s % 8 takes it as its (s / 8)-th chunk); cost[] is zeroed for the
 // next frame
-hipError_t launch_order_chunks(unsigned long long* cost, uint32_t* order, uint32_t n_chunks, hipStream_t stream);
+hipError_t launch_order_chunks(unsigned long long* cost, uint32_t* order, uint32_t n_chunks, uint32_t spp, hipStream_t stream);
 hipError_t launch_arith(uint32_t op, const float* a, const float* b, const float* c, float* out,
                         uint32_t n, hipStream_t stream);
 

@@ -1785,23 +1785,43 @@ __global__ void arith_kernel(uint32_t op, const float* a, const float* b, const 
 // chunk order for the next frame (cost-ordered dequeue): one workgroup, counting sort on 1024 cost classes
 // ============================================================================
 constexpr uint32_t kOrderBins = 1024;
-__global__ __launch_bounds__(1024) void order_chunks_kernel(unsigned long long* cost, uint32_t* order, uint32_t n) {
-    __shared__ unsigned long long top;
+// Classes on a fixed scale, so that one look at the costs suffices for the histogram: a chunk's cost over the samples
+// of one of its pixels is 32 x its mean segments per sample; class = 1023 - (that - 32), clamped: steps of 1/32 segment
+// from a mean of 1 (sky: every path one segment) to a mean of 33, anything dearer in class 0.  (The first version
+// looked for the largest cost first: three passes of thirty dependent-latency loads per thread, 46 us per frame of the
+// cover scene, serial behind the path kernel.  Loads are issued eight at a time now.)
+DI uint32_t cost_class(unsigned long long cost, float inv_spp) {
+    const float units = static_cast<float>(cost) * inv_spp - 32.0f;
+    const float c = units > 0.0f ? (units < static_cast<float>(kOrderBins - 1u) ? units : static_cast<float>(kOrderBins - 1u)) : 0.0f;
+    return (kOrderBins - 1u) - static_cast<uint32_t>(c);
+}
+__global__ __launch_bounds__(1024) void order_chunks_kernel(unsigned long long* cost, uint32_t* order, uint32_t n, float inv_spp) {
     __shared__ uint32_t first[kOrderBins];  // histogram, then the first place of each class
+    __shared__ uint32_t any;
     const uint32_t t = threadIdx.x;
-    if (t == 0u) top = 0ull;
     first[t] = 0u;
+    if (t == 0u) any = 0u;
     __syncthreads();
-    unsigned long long mine = 0ull;
-    for (uint32_t c = t; c < n; c += kOrderBins) mine = cost[c] > mine ? cost[c] : mine;
-    if (mine != 0ull) atomicMax(&top, mine);
-    __syncthreads();
-    const unsigned long long hi = top;
-    // class 0 = dearest; costs are below 2^48 (256 pixels x 2^32), the product below 2^58
-    auto cls = [&](unsigned long long c) {
-        return hi == 0ull ? 0u : (kOrderBins - 1u) - static_cast<uint32_t>(c * (kOrderBins - 1u) / hi);
-    };
-    for (uint32_t c = t; c < n; c += kOrderBins) atomicAdd(&first[cls(cost[c])], 1u);
+    constexpr uint32_t kBatch = 8;
+    bool seen = false;
+    for (uint32_t c0 = t; c0 < n; c0 += kBatch * kOrderBins) {
+        unsigned long long v[kBatch];
+#pragma unroll
+        for (uint32_t u = 0; u < kBatch; ++u) v[u] = c0 + u * kOrderBins < n ? cost[c0 + u * kOrderBins] : 0ull;
+#pragma unroll
+        for (uint32_t u = 0; u < kBatch; ++u) {
+            // (a third of the cover frame is sky, all of it in the last class: those lanes are counted with a
+            // ballot instead of ten thousand LDS atomics on one word)
+            const bool in = c0 + u * kOrderBins < n;
+            const uint32_t k = in ? cost_class(v[u], inv_spp) : 0u;
+            const bool last = in && k == kOrderBins - 1u;
+            const unsigned long long m = __ballot(last);
+            if (in && !last) atomicAdd(&first[k], 1u);
+            if ((t & 63u) == 0u && m != 0ull) atomicAdd(&first[kOrderBins - 1u], static_cast<uint32_t>(__popcll(m)));
+            seen = seen || (in && v[u] != 0ull);
+        }
+    }
+    if (seen) any = 1u;
     __syncthreads();
     // exclusive prefix sum over the classes (thread t owns class t): Hillis-Steele in LDS
     uint32_t incl = first[t];
@@ -1818,20 +1838,37 @@ __global__ __launch_bounds__(1024) void order_chunks_kernel(unsigned long long* 
     // place s of the sequence belongs to queue s % 8, which reads it as its (s / 8)-th chunk: stored queue by queue
     const uint32_t per_queue = (n + 7u) / 8u;
     auto slot_of = [&](uint32_t seq) { return (seq & 7u) * per_queue + (seq >> 3); };
-    if (hi == 0ull) {  // nothing measured: natural order
+    if (any == 0u) {  // nothing measured: natural order
         for (uint32_t c = t; c < n; c += kOrderBins) order[slot_of(c)] = c;
         return;
     }
-    for (uint32_t c = t; c < n; c += kOrderBins) {
-        order[slot_of(atomicAdd(&first[cls(cost[c])], 1u))] = c;
-        cost[c] = 0ull;
+    for (uint32_t c0 = t; c0 < n; c0 += kBatch * kOrderBins) {
+        unsigned long long v[kBatch];
+#pragma unroll
+        for (uint32_t u = 0; u < kBatch; ++u) v[u] = c0 + u * kOrderBins < n ? cost[c0 + u * kOrderBins] : 0ull;
+#pragma unroll
+        for (uint32_t u = 0; u < kBatch; ++u) {
+            const bool in = c0 + u * kOrderBins < n;
+            const uint32_t k = in ? cost_class(v[u], inv_spp) : 0u;
+            const bool last = in && k == kOrderBins - 1u;
+            const unsigned long long m = __ballot(last);
+            uint32_t base = 0u;
+            if ((t & 63u) == 0u && m != 0ull) base = atomicAdd(&first[kOrderBins - 1u], static_cast<uint32_t>(__popcll(m)));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (in) {
+                const uint32_t place = last ? base + lane_rank(m) : atomicAdd(&first[k], 1u);
+                order[slot_of(place)] = c0 + u * kOrderBins;
+                cost[c0 + u * kOrderBins] = 0ull;
+            }
+        }
     }
 }
 
 }  // namespace
 
-hipError_t launch_order_chunks(unsigned long long* cost, uint32_t* order, uint32_t n_chunks, hipStream_t stream) {
-    hipLaunchKernelGGL(order_chunks_kernel, dim3(1), dim3(kOrderBins), 0, stream, cost, order, n_chunks);
+hipError_t launch_order_chunks(unsigned long long* cost, uint32_t* order, uint32_t n_chunks, uint32_t spp, hipStream_t stream) {
+    hipLaunchKernelGGL(order_chunks_kernel, dim3(1), dim3(kOrderBins), 0, stream, cost, order, n_chunks,
+                       1.0f / static_cast<float>(spp ? spp : 1u));
     return hipGetLastError();
 }
 
