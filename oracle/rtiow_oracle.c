@@ -583,7 +583,7 @@ int oracle_write_ppm(const char* path, const uint8_t* rgba8, uint32_t W, uint32_
     return RT_OK;
 }
 
-/* ---- arithmetic conformance probes (CPU side of tests/test_arith_gpu.py) ---
+/* ---- arithmetic conformance probes (CPU side of tests/test_gpu_parity.py::test_arith_bit_exact) ---
  * op: 0 fma(a,b,c) 1 a/b 2 sqrt(a) 3 a*b 4 a+b 5 rng: 4th draw of stream (seed=a bits,
  * pixel=c bits, sample 7) 6 (float)(to_fixed(a)+to_fixed(b)) [fixed-point accumulate +
  * u64->float rounding] 7 (float)(u64 built from the bits of a (high) and b (low)) */

@@ -244,7 +244,9 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
     // One frame in flight per context: the counters (with the pixel queues' heads), the timing events, the
     // accumulators and the chunk order are the context's.  A render on another stream than the last one's
     // waits, on the device, for everything the last one enqueued.
-    if (ctx->have_done && stream != ctx->last_stream) RT_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_done, 0));
+    // (The reference's own kernels keep no state in the context -- no queues, no counters -- and their frame is
+    // launch-bound: they neither wait nor leave an event behind.)
+    if (!is_ch && ctx->have_done && stream != ctx->done_stream) RT_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_done, 0));
     ctx->last_stream = stream;
     // progressive accumulation: the accumulators belong to one (size, tile) frame; a new frame starts at
     // sample_offset 0.  (Checked and recorded before the empty-tile return: a rank that owns no rows still
@@ -388,8 +390,11 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
                                      rows, hipMemcpyDeviceToHost, stream));
         RT_HIP(ctx, hipStreamSynchronize(stream));
     }
-    RT_HIP(ctx, hipEventRecord(ctx->ev_done, stream));
-    ctx->have_done = true;
+    if (!is_ch) {
+        RT_HIP(ctx, hipEventRecord(ctx->ev_done, stream));
+        ctx->have_done = true;
+        ctx->done_stream = stream;
+    }
     return RT_OK;
 }
 

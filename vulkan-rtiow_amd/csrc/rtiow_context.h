@@ -16,6 +16,7 @@ struct RtContext {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipEvent_t ev_done = nullptr;  // end of everything the last render enqueued (its stream may differ from the next one's)
     bool have_done = false;
+    hipStream_t done_stream = nullptr;  // the stream ev_done was recorded on
     float4* d_spheres = nullptr;
     rtiow::ShadeRec* d_shade = nullptr;
     float4* d_cslots = nullptr;   // clustered list (rtiow_clusters.cpp)

@@ -1,10 +1,17 @@
 // rtiow_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the
 // per-pixel path-tracing hot path.
 //
-//   ch_kernel            raytrace05.comp / raytrace06.comp (the reference's two
-//                        compute shaders), one lane per pixel, packed RGBA8 store
-//   path_pixel_kernel    PATH mode v1: one lane per pixel, spp + bounce loops inside,
-//                        sphere list staged in LDS once per workgroup
+//   ch_kernel               raytrace05.comp / raytrace06.comp (the reference's two compute shaders), one lane
+//                           per pixel, packed RGBA8 store
+//   path_pixel_kernel       PATH mode v1 (RtParams.kernel 1): one lane per pixel, spp + bounce loops inside, sphere
+//                           list staged in LDS once per workgroup; kept as a cross-check and ablation
+//   path_persistent_kernel  PATH mode v2, four instantiations <shading records in LDS?, clustered list?>: persistent
+//                           waves, two path slots per lane, per-XCD pixel queues, LDS accumulators, in-kernel resolve.
+//                           <., false> walks the flat sphere list (kernel 2; default below 64 spheres), <., true> the
+//                           two-level clustered list (kernel 3; default from 64 spheres on)
+//   order_chunks_kernel     the next frame's chunk sequence from this frame's per-chunk costs (cost-ordered dequeue)
+//   arith_kernel            one operation per element: the arithmetic conformance probe of rtSelfTestArith
+//   (deinterleave_kernel, the multi-GPU frame assembly, lives in rtiow_multi.hip)
 //
 // Arithmetic contract: binary32, round-to-nearest-even, denormals kept, only
 // + - * / sqrt and fma; compiled with -ffp-contract=off so a fused multiply-add
@@ -1753,7 +1760,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
 }
 
 // ============================================================================
-// arithmetic conformance probe (tests/test_gpu_arith.py)
+// arithmetic conformance probe (tests/test_gpu_parity.py::test_arith_bit_exact)
 // ============================================================================
 __global__ void arith_kernel(uint32_t op, const float* a, const float* b, const float* c,
                              float* out, uint32_t n) {
