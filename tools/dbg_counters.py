@@ -7,7 +7,7 @@ spp = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 w = int(sys.argv[2]) if len(sys.argv) > 2 else 1200
 h = int(sys.argv[3]) if len(sys.argv) > 3 else 800
 kernel = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-sph, mat = V.make_cover_scene(1, 11)
+sph, mat = V.make_cover_scene(1, int(os.environ.get("GRID", "11")))
 cam = V.make_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, w / h, 0.1, 10.0)
 with V.Context(0) as ctx:
     ctx.set_scene(sph, mat)

@@ -817,7 +817,10 @@ DI void walk_clusters(const float4* slots, const uint32_t* idx_map, const PathAr
     }
 }
 
-template <int R>
+// SUPER: the instantiation can meet super-clusters (a.n_super != 0).  Small scenes -- those whose shading records sit
+// in LDS, at most ~580 spheres -- never have them (kSuperFrom clusters = 1536 spheres): their kernel is compiled
+// without that level, which is a third of this function and would otherwise weigh on its register allocation.
+template <int R, bool SUPER>
 DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const float4* bounds, const PathArgs& a,
                         uint16_t* items, unsigned long long* results,
                         Slot (&sl)[R], float (&best)[R], int (&best_i)[R], uint32_t (&best_o)[R],
@@ -921,7 +924,7 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
             }
         }
     }
-    if (a.n_super == 0u) {
+    if (!SUPER || a.n_super == 0u) {
         // ---- phases 1 and 2, 32 clusters at a time ----
         for (uint32_t g0 = 0; g0 < a.n_clusters; g0 += 32u) {
             uint32_t miss[R];
@@ -1155,7 +1158,7 @@ DI void sparse_members(const float4* slots, const uint32_t* idx_map, const PathA
     }
 }
 
-template <int R>
+template <int R, bool SUPER>
 DI void trace_sparse_parallel(const float4* slots, const uint32_t* idx_map, const float4* bounds, const PathArgs& a,
                               uint16_t* items, unsigned long long* results, Slot (&sl)[R], float (&best)[R],
                               int (&best_i)[R], uint32_t (&best_o)[R], uint32_t& n_tests) {
@@ -1180,7 +1183,7 @@ DI void trace_sparse_parallel(const float4* slots, const uint32_t* idx_map, cons
     }
     if (lane < n_live) keys[lane] = ~0ull;
     // (a wave's LDS operations are performed in order: rays and keys are in place for what follows)
-    const bool two_level = a.n_super != 0u;
+    const bool two_level = SUPER && a.n_super != 0u;
     const float4* top = two_level ? bounds + 2u * a.n_clusters : bounds;
     const uint32_t n_top = two_level ? a.n_super : a.n_clusters;
     uint16_t* top_items = two_level ? items + kItemCap : items;
@@ -1561,7 +1564,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             // few paths left: gather them in slot 0 (the shade and refill code below then runs once, not
             // once per slot), then trace them together
             compact_to_slot0(sl, reinterpret_cast<uint32_t*>(lds_results));
-            trace_sparse_parallel<kSlots>(lds_spheres, lds_cidx, lds_cbounds, a, lds_items, lds_results, sl, best, best_i,
+            trace_sparse_parallel<kSlots, !SHADE_LDS>(lds_spheres, lds_cidx, lds_cbounds, a, lds_items, lds_results, sl, best, best_i,
                                           best_o, n_tests);
             TL_MARK(tl_sparse);
 #ifdef RTIOW_DEBUG_TIMELINE
@@ -1583,7 +1586,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 if (sl[r].active) n_tests += a.n;
             DBG_ADD(dbg_sparse, lane == 0u ? 1u : 0u);
         } else if (ACCEL) {
-            trace_clustered<kSlots>(lds_spheres, lds_cidx, lds_cbounds, a, lds_items, lds_results, sl, best, best_i, best_o, n_tests,
+            trace_clustered<kSlots, !SHADE_LDS>(lds_spheres, lds_cidx, lds_cbounds, a, lds_items, lds_results, sl, best, best_i, best_o, n_tests,
                                     dbg_slow_trips, dbg_cands, dbg_t_slow);
         } else {
             trace_slots<kSlots>(lds_spheres, g.n_pad, a.n, sl, best, best_i, dbg_slow_trips, dbg_cands, dbg_t_slow);
@@ -1597,6 +1600,20 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         [[maybe_unused]] const unsigned long long t2 = DBG_STAMP();
 
         // ---- shade ----------------------------------------------------------
+        // Large scenes keep their shading records in HBM/L2: the records of BOTH slots' hits are asked for here, so that
+        // the second slot's round trip (about a microsecond under load) passes while the first slot is shaded.
+        [[maybe_unused]] float4 rec0[kSlots], rec1[kSlots];
+        if (!SHADE_LDS) {
+#pragma unroll
+            for (int r = 0; r < kSlots; ++r) {
+                rec0[r] = rec1[r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (sl[r].active && best_i[r] >= 0) {
+                    const float4* src = reinterpret_cast<const float4*>(a.shade + best_o[r]);
+                    rec0[r] = src[0];
+                    rec1[r] = src[1];
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < kSlots; ++r) {
             Slot& q = sl[r];
@@ -1619,7 +1636,8 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                         m.albedo[0] = m0.x; m.albedo[1] = m0.y; m.albedo[2] = m0.z; m.param = m0.w;
                         m.inv_r = m1.x; m.kind = __float_as_uint(m1.y);
                     } else {
-                        m = a.shade[best_o[r]];
+                        m.albedo[0] = rec0[r].x; m.albedo[1] = rec0[r].y; m.albedo[2] = rec0[r].z; m.param = rec0[r].w;
+                        m.inv_r = rec1[r].x; m.kind = __float_as_uint(rec1[r].y);
                     }
                     if (!scatter(mk(geo.x, geo.y, geo.z), m, best[r], q.p)) {
                         finished = true;  // absorbed: radiance 0
@@ -1938,6 +1956,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     const bool shade_lds = lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 28u * 1024u &&
                            !getenv("RTIOW_DEBUG_NO_SHADE_LDS");  // (tuning only)
     const size_t lds_scene = lds_geo + (shade_lds ? static_cast<size_t>(a.n) * sizeof(ShadeRec) : 0u);
+    if (shade_lds && a.n_super != 0u) return hipErrorInvalidValue;  // (cannot happen: see trace_clustered's SUPER)
     const size_t lds_wave = kWaveAccBytes + kWaveLineBytes + (accel ? item_bytes : 0u);
     void (*kernel_fn)(PathArgs, PersistArgs) =
         accel ? (shade_lds ? path_persistent_kernel<true, true> : path_persistent_kernel<false, true>)
