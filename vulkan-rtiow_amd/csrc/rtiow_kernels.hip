@@ -1413,16 +1413,12 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     for (;;) {
         [[maybe_unused]] const unsigned long long t0 = DBG_STAMP();
         // ---- refill ---------------------------------------------------------
-        bool any_active = false;
-#pragma unroll
-        for (int r = 0; r < kSlots; ++r) {
-            Slot& q = sl[r];
-            const unsigned long long mask = __ballot(!q.active);  // idle slots: one sample each
-            const uint32_t want = static_cast<uint32_t>(__popcll(mask));
-            const uint32_t rank = lane_rank(mask);
-            uint32_t served = 0u;  // wave-uniform: idle lanes already given a sample this round
-            uint32_t my_s = 0u;
-            bool got_sample = false;
+        // Hands out the next `want` samples of the wave's pool, pixel by pixel: on_range(first, n, pixel, entry, sample)
+        // is told that the idle slots numbered first .. first+n-1 get samples sample .. sample+n-1 of that pixel (whose
+        // line buffer is cur_line).  Returns how many were handed out (fewer than `want` once the queues are dry or the
+        // accumulator entries are all in use).
+        auto hand_out = [&](uint32_t want, auto&& on_range) -> uint32_t {
+            uint32_t served = 0u;  // wave-uniform
             while (served < want) {  // one trip per pixel touched (1-2 unless spp is tiny)
                 if (cur_s == a.spp) {  // open the next pixel of the pool
                     if (pool_next == pool_end) {
@@ -1521,25 +1517,91 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     if (lane < kAccWords) lds_acc[(wave_in_group * kAccEntries + cur_entry) * kAccWords + lane] = 0ull;
                 }
                 const uint32_t n = want - served < a.spp - cur_s ? want - served : a.spp - cur_s;
-                if (!q.active && rank >= served && rank < served + n) {
-                    q.pix = cur_pix;
-                    q.entry = wave_in_group * kAccEntries + cur_entry;
-                    q.line = cur_line;
-                    my_s = cur_s + (rank - served);
-                    got_sample = true;
-                }
+                on_range(served, n, cur_pix, wave_in_group * kAccEntries + cur_entry, cur_s);
                 cur_s += n;
                 served += n;
             }
-            if (got_sample) {  // start the sample
-                const uint32_t lr = q.pix / a.width, i = q.pix - lr * a.width;
-                const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
-                camera_path(a, i, j, a.sample_offset + my_s, q.p);
-                q.depth = 0u;
-                q.active = true;
-                ++n_paths;
+            return served;
+        };
+        bool any_active = false;
+        const unsigned long long idle0 = __ballot(!sl[0].active), idle1 = __ballot(!sl[1].active);
+        const uint32_t n_idle0 = static_cast<uint32_t>(__popcll(idle0));
+        const uint32_t n_idle = n_idle0 + static_cast<uint32_t>(__popcll(idle1));
+        if (ACCEL && SHADE_LDS && n_idle <= 64u) {
+            // The usual case (a third of the 128 slots finish per iteration): the idle slots are numbered across both
+            // slots, lane k generates the camera path of number k -- ONE pass of the camera code on n_idle of 64 lanes
+            // instead of one pass per slot on a third of the lanes each -- and leaves it in the wave's LDS scratch
+            // (the trace's work-list area, idle now), where the lane that owns slot number k picks it up.
+            if (n_idle != 0u) {
+                const uint32_t my_idx[kSlots] = {lane_rank(idle0), n_idle0 + lane_rank(idle1)};
+                bool got[kSlots] = {false, false};
+                uint32_t gen_pix = 0u, gen_s = 0u;
+                const uint32_t granted = hand_out(n_idle, [&](uint32_t first, uint32_t n, uint32_t pix, uint32_t entry, uint32_t s0) {
+                    if (lane - first < n) {  // (unsigned: first <= lane < first + n)
+                        gen_pix = pix;
+                        gen_s = s0 + (lane - first);
+                    }
+#pragma unroll
+                    for (int r = 0; r < kSlots; ++r)
+                        if (!sl[r].active && my_idx[r] - first < n) {
+                            sl[r].pix = pix;
+                            sl[r].entry = entry;
+                            sl[r].line = cur_line;
+                            got[r] = true;
+                        }
+                });
+                float4* rec = reinterpret_cast<float4*>(lds_results);  // [64] {o, d.x} then [64] {d.y, d.z, rng, -}
+                if (lane < granted) {
+                    Path np;
+                    const uint32_t lr = gen_pix / a.width, i = gen_pix - lr * a.width;
+                    const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
+                    camera_path(a, i, j, a.sample_offset + gen_s, np);
+                    rec[lane] = make_float4(np.o.x, np.o.y, np.o.z, np.du.x);
+                    rec[64u + lane] = make_float4(np.du.y, np.du.z, __uint_as_float(np.rng.state), 0.0f);
+                }
+#pragma unroll
+                for (int r = 0; r < kSlots; ++r) {
+                    Slot& q = sl[r];
+                    if (got[r]) {  // (a wave's LDS operations are performed in order: the record is there)
+                        const float4 r0 = rec[my_idx[r]], r1 = rec[64u + my_idx[r]];
+                        q.p.o = mk(r0.x, r0.y, r0.z);
+                        q.p.du = mk(r0.w, r1.x, r1.y);
+                        q.p.rng = Pcg(__float_as_uint(r1.z));
+                        q.p.att = mk(1.0f, 1.0f, 1.0f);
+                        q.depth = 0u;
+                        q.active = true;
+                        ++n_paths;
+                    }
+                }
             }
-            any_active = any_active || q.active;
+            any_active = sl[0].active || sl[1].active;
+        } else {
+#pragma unroll
+            for (int r = 0; r < kSlots; ++r) {  // slot by slot: the flat-list kernel (no scratch), and bursts of > 64 idle slots
+                Slot& q = sl[r];
+                const unsigned long long mask = r == 0 ? idle0 : idle1;
+                const uint32_t rank = lane_rank(mask);
+                uint32_t my_s = 0u;
+                bool got_sample = false;
+                hand_out(static_cast<uint32_t>(__popcll(mask)), [&](uint32_t first, uint32_t n, uint32_t pix, uint32_t entry, uint32_t s0) {
+                    if (!q.active && rank - first < n) {
+                        q.pix = pix;
+                        q.entry = entry;
+                        q.line = cur_line;
+                        my_s = s0 + (rank - first);
+                        got_sample = true;
+                    }
+                });
+                if (got_sample) {  // start the sample
+                    const uint32_t lr = q.pix / a.width, i = q.pix - lr * a.width;
+                    const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
+                    camera_path(a, i, j, a.sample_offset + my_s, q.p);
+                    q.depth = 0u;
+                    q.active = true;
+                    ++n_paths;
+                }
+                any_active = any_active || q.active;
+            }
         }
         // No live path anywhere in the wave: every slot asked and got nothing, so the pool is
         // used up and the global queue drained (an entry shortage needs live paths to exist).
