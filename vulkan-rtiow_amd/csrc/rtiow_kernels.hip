@@ -696,14 +696,22 @@ DI void examine_cluster(const float4* slots, const uint32_t* idx_map, uint32_t b
                         const float oy, const float oz, const float dx, const float dy, const float dz,
                         unsigned long long& key) {
     uint32_t mm = 0u;
+    // four members per step, their reads issued together (left to itself the compiler keeps two reads in flight and
+    // waits for each after eleven instructions; an LDS read with per-lane addresses takes longer than that)
 #pragma unroll
-    for (uint32_t k = 0; k < kClusterSize; ++k) {
-        const float4 s = slots[base + ((k + lane) & (kClusterSize - 1u))];
-        const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
-        const float hb = fma_(ocz, dz, fma_(ocy, dy, ocx * dx));
-        const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
-        const float disc = fma_(hb, hb, -cc);
-        mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(disc), 31);
+    for (uint32_t k0 = 0; k0 < kClusterSize; k0 += 4u) {
+        float4 s4[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) s4[u] = slots[base + ((k0 + u + lane) & (kClusterSize - 1u))];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const float4 s = s4[u];
+            const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
+            const float hb = fma_(ocz, dz, fma_(ocy, dy, ocx * dx));
+            const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
+            const float disc = fma_(hb, hb, -cc);
+            mm = __builtin_amdgcn_alignbit(mm, __float_as_uint(disc), 31);
+        }
     }
     uint32_t cand = ~mm & (0xFFFFFFFFu >> (32u - kClusterSize));  // bit kClusterSize-1-k: member step k
     while (cand) {
