@@ -20,9 +20,10 @@ def _pattern(rows, width):
     return ((rows[:, None] * 7919 + x * 104729) % (2**31 - 1)).astype(np.int32)
 
 
-def _worker(rank, world, port, height, width, block, out_path):
+def _worker(rank, world, port, height, width, block, out_path, collective="gather"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    D._collective = collective
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rows = D.tile_rows(height, block, rank, world)
     assert len(rows) == V.tile_row_count(height, block, rank, world)
@@ -51,6 +52,15 @@ def test_gather_reassembles_frame(tmp_path, world, height, width, block):
     mp.spawn(_worker, args=(world, _free_port(), height, width, block, out), nprocs=world, join=True)
     got = np.load(out)
     assert np.array_equal(got, _pattern(np.arange(height), width))
+
+
+def test_all_gather_form_reassembles_the_same_frame(tmp_path):
+    """The form dist.gather_frame falls back to when the backend refuses a rooted gather (RTIOW_COLLECTIVE=all_gather
+    selects it outright): same padded slots, same de-interleave, same frame."""
+    world, height, width, block = 3, 41, 11, 4
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), height, width, block, out, "all_gather"), nprocs=world, join=True)
+    assert np.array_equal(np.load(out), _pattern(np.arange(height), width))
 
 
 def test_single_rank_is_identity():

@@ -68,13 +68,34 @@ def gather_frame(local: torch.Tensor, height: int, row_block: int, rank: int, wo
         send = torch.zeros((pad_rows, width), dtype=local.dtype, device=local.device)
         send[: local.shape[0]] = local
     send = send.contiguous()
-    if rank == dst:
-        # one receive buffer [world, pad_rows, width]; one scatter of its rows into the frame
-        # (plus a scratch row that swallows the padding)
-        recv = torch.empty((world, pad_rows, width), dtype=local.dtype, device=local.device)
-        dist.gather(send, gather_list=list(recv.unbind(0)), dst=dst, group=group)
-        frame = torch.empty((height + 1, width), dtype=local.dtype, device=local.device)
-        frame.index_copy_(0, _scatter_rows(height, row_block, world, local.device), recv.view(world * pad_rows, width))
-        return frame[:height]
-    dist.gather(send, gather_list=None, dst=dst, group=group)
-    return None
+    global _collective
+    if _collective == "gather":
+        try:
+            if rank == dst:
+                # one receive buffer [world, pad_rows, width]; one scatter of its rows into the frame
+                # (plus a scratch row that swallows the padding)
+                recv = torch.empty((world, pad_rows, width), dtype=local.dtype, device=local.device)
+                dist.gather(send, gather_list=list(recv.unbind(0)), dst=dst, group=group)
+                return _deinterleave(recv, height, row_block, world)
+            dist.gather(send, gather_list=None, dst=dst, group=group)
+            return None
+        except (RuntimeError, NotImplementedError) as exc:
+            # A backend without a rooted gather refuses the call on every rank alike, before anything is sent: all of
+            # them fall through to the all-gather form together.  (The RCCL gather has not run on hardware yet.)
+            import warnings
+            warnings.warn(f"dist.gather refused ({exc}); using all_gather_into_tensor for the frame")
+            _collective = "all_gather"
+    recv = torch.empty((world, pad_rows, width), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(recv.view(world * pad_rows, width), send, group=group)
+    return _deinterleave(recv, height, row_block, world) if rank == dst else None
+
+
+# "gather" (the default: only the root receives) or "all_gather" (RTIOW_COLLECTIVE=all_gather, or after a refusal)
+_collective = __import__("os").environ.get("RTIOW_COLLECTIVE", "gather")
+
+
+def _deinterleave(recv: torch.Tensor, height: int, row_block: int, world: int) -> torch.Tensor:
+    pad_rows, width = recv.shape[1], recv.shape[2]
+    frame = torch.empty((height + 1, width), dtype=recv.dtype, device=recv.device)
+    frame.index_copy_(0, _scatter_rows(height, row_block, world, recv.device), recv.view(world * pad_rows, width))
+    return frame[:height]
