@@ -355,6 +355,7 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         const bool ordered = kernel != rtiow::KERNEL_PIXEL && !getenv("RTIOW_DEBUG_NO_ORDER");  // (tuning only)
 #endif
         const uint32_t n_chunks = rtiow::chunk_count(rows, W);
+        bool collect = false;
         if (ordered) {
             const uint64_t okey = ((uint64_t(W) << 40) ^ (uint64_t(H) << 20) ^ (uint64_t(rblock) << 12) ^
                                    (uint64_t(prm->tile_rank) << 6) ^ uint64_t(tcount)) + 1u;
@@ -368,13 +369,20 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
                 RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, size_t(n_chunks) * 8u, stream));
                 ctx->order_valid = false;
                 ctx->order_key = okey;
+                ctx->order_frames = 0;
             }
-            a.chunk_cost = ctx->d_chunk_cost;
+            // The first two frames of a shape report their costs and have them sorted (the second one runs in the order
+            // of the first), after that every eighth: a frame loop over a scene that changes slowly, if at all, does
+            // not need a new order per frame, and seven frames in eight then pay neither the cost reports nor the
+            // 32 us of sorting behind the path kernel.
+            collect = ctx->order_frames < 2u || ctx->order_frames % 8u == 0u;
+            ++ctx->order_frames;
+            a.chunk_cost = collect ? ctx->d_chunk_cost : nullptr;
             a.chunk_order = ctx->order_valid ? ctx->d_chunk_order : nullptr;
         }
         RT_HIP(ctx, rtiow::launch_path(a, kernel, prm->chunk_spp, ctx->num_cus, stream, &ctx->last_kernel));
         RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream));
-        if (ordered) {
+        if (ordered && collect) {
             RT_HIP(ctx, rtiow::launch_order_chunks(ctx->d_chunk_cost, ctx->d_chunk_order, n_chunks, prm->spp, stream));
             ctx->order_valid = true;
         }

@@ -42,6 +42,7 @@ struct RtContext {
     size_t chunk_order_bytes = 0;
     uint64_t order_key = 0;                 // (size, tile) the order belongs to
     bool order_valid = false;
+    uint32_t order_frames = 0;              // frames of this shape rendered so far
     uint64_t accum_key = 0;                 // which frame the accumulators belong to
     uint32_t accum_samples = 0;             // samples accumulated so far
     bool have_timing = false;
