@@ -111,6 +111,9 @@ def main():
                          "keeps one compute fence per swapchain image (RTCHAP06/main.cpp:94-98,313-316).  Default 1 at "
                          "every N, so that `value` compares like with like across N; the rate with three frames in "
                          "flight is measured after the timed loop and reported beside it (config.three_frames_in_flight)")
+    ap.add_argument("--no-gather-overlap", action="store_true",
+                    help="N > 1: run the frame gather on the rendering stream instead of a side stream (where it runs beside "
+                         "the next frame's rendering, the tile double-buffered)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extras (two frames in flight, the other kernel): profiling runs")
@@ -166,7 +169,35 @@ def main():
         locals_.append(torch.zeros((rows, w), dtype=torch.int32, device=dev))
     ctx = ctxs[0]
 
+    # N > 1, one frame in flight: the gather of frame k (and its de-interleave on rank 0) runs on a side stream beside the
+    # RENDERING of frame k + 1 -- communication under computation, still one frame being rendered at a time.  Two tile
+    # buffers; a tile is rendered into again only when its previous gather has read it.
+    overlap = world > 1 and F == 1 and not args.no_gather_overlap
+    if overlap:
+        gstream = torch.cuda.Stream(device=dev)
+        tiles = [locals_[0], torch.zeros_like(locals_[0])]
+        rendered = [torch.cuda.Event(), torch.cuda.Event()]
+        gathered = [None, None]
+
     def step(k, events=None):
+        if overlap:
+            b = k % 2
+            with torch.cuda.stream(streams[0]):
+                if gathered[b] is not None:
+                    streams[0].wait_event(gathered[b])
+                if events is not None:
+                    events[0].record()
+                ctxs[0].render_device(cam, prm, tiles[b].data_ptr(), w * 4, streams[0].cuda_stream)
+                if events is not None:
+                    events[1].record()
+                rendered[b].record()
+            with torch.cuda.stream(gstream):
+                gstream.wait_event(rendered[b])
+                out = D.gather_frame(tiles[b], h, prm.row_block, rank, world)
+                done = torch.cuda.Event()
+                done.record()
+                gathered[b] = done
+            return out
         i = k % F
         with torch.cuda.stream(streams[i]):
             if events is not None:
@@ -207,6 +238,17 @@ def main():
         elapsed, kernel_ms_max, segments = tmax[0].item(), tmax[1].item(), tsum[2].item()
     else:
         kernel_ms_max, segments = kernel_ms, float(st.segments)
+
+    # N > 1: the last gathered frame against the same frame rendered whole by rank 0 alone (outside the timed region)
+    frame_check = None
+    if world > 1 and rank == 0 and frame is not None:
+        whole = torch.zeros((h, w), dtype=torch.int32, device=dev)
+        wprm = V.make_params(w, h, spp=spp, max_depth=depth, seed=1, chunk_spp=args.chunk_spp, quantiser=V.RT_QUANT_BOOK,
+                             kernel=args.kernel)
+        with torch.cuda.stream(streams[0]):
+            ctx.render_device(cam, wprm, whole.data_ptr(), w * 4, streams[0].cuda_stream)
+        torch.cuda.synchronize()
+        frame_check = "identical" if bool(torch.equal(frame.to(dev), whole)) else "DIFFERS"
 
     # The same loop with three frames in flight (three contexts / streams / tile buffers per rank, as the
     # reference's per-swapchain-image fences allow): measured at EVERY N, after the timed region, never `value`.
@@ -291,6 +333,8 @@ def main():
                        "partition": (f"row-tiles block-cyclic x{args.row_block} over {world} GPUs + RCCL gather"
                                      if world > 1 else "single GPU"),
                        "frames_in_flight": F,
+                       "gather": ("side stream: frame k's gather runs beside the rendering of frame k + 1 (two tile buffers)"
+                                  if overlap else ("on the rendering stream" if world > 1 else "none (one GPU)")),
                        "segments_per_frame": int(segments), "segments_per_s": segments / (elapsed / args.steps),
                        "sphere_tests_per_s": st.sphere_tests * (segments / max(1, st.segments)) / (elapsed / args.steps),
                        "tests_per_segment": st.sphere_tests / max(1, st.segments),
@@ -320,6 +364,8 @@ def main():
         quick = ms_per_step < 500.0 and not args.no_extras  # the extras below re-render the frame a few times
         if inflight3 is not None:
             out["config"]["three_frames_in_flight"] = inflight3
+        if frame_check is not None:
+            out["config"]["gathered_frame_vs_single_gpu_frame"] = frame_check
         if world == 1 and quick:  # the other persistent kernel on the same frame, outside the timed region
             other = 3 if eff_kernel == 2 else 2
             oprm = V.make_params(w, h, spp=spp, max_depth=depth, seed=1, quantiser=V.RT_QUANT_BOOK, kernel=other)
