@@ -147,6 +147,35 @@ def test_config5_at_its_stated_1024spp_rows_vs_oracle(gpu_ctx, oracle):
     assert np.array_equal(full[rows], want)
 
 
+def test_full_size_progressive_and_pitch_with_whole_chunk_pools(gpu_ctx, oracle):
+    """At full size a wave takes whole 32-pixel chunks and writes each 128-byte line at once (rtiow_kernels.hip, line
+    buffers).  Here that path runs with everything that touches its addressing: progressive accumulation (two dispatches
+    of 3 + 5 spp == one of 8), a destination pitch wider than the row (device buffer), 1200 not being a multiple of 32
+    (chunks that run over the end of a row) and both persistent kernels; every 40th row against the oracle at 8 spp."""
+    torch = pytest.importorskip("torch")
+    w, h = 1200, 800
+    sph, mat, cam = _cover(w, h)
+    base = V.make_params(w, h, spp=8, max_depth=50, seed=3)
+    want, _ = _oracle_rows(oracle, sph, mat, cam, base, 40)
+    pitch_px = 1216
+    for kernel in (V.KERNEL_CLUSTERED, V.KERNEL_PERSISTENT):
+        ctx = V.Context(0)
+        ctx.set_scene(sph, mat)
+        buf = torch.full((h, pitch_px), 0x7F7F7F7F, dtype=torch.int32, device="cuda:0")
+        ts = torch.cuda.Stream()
+        ts.wait_stream(torch.cuda.current_stream())
+        done = 0
+        for spp in (3, 5):
+            prm = V.make_params(w, h, spp=spp, max_depth=50, seed=3, kernel=kernel, sample_offset=done, accumulate=1)
+            ctx.render_device(cam, prm, buf.data_ptr(), pitch_px * 4, ts.cuda_stream)
+            done += spp
+        ts.synchronize()
+        host = buf.cpu().numpy().view(np.uint8).reshape(h, pitch_px, 4)
+        assert np.array_equal(host[::40, :w], want), kernel
+        assert (host[:, w:] == 0x7F).all()
+        ctx.close()
+
+
 def test_many_samples_one_pixel_row(gpu_ctx, oracle):
     """spp larger than a pool (pool = 1 pixel): 5000 spp on a 16x2 image, and spp = 1."""
     w, h = 16, 2
