@@ -60,6 +60,19 @@ def test_harness_scene_file_progressive_matches_oracle(oracle, tmp_path):
     assert np.array_equal(_read_ppm(out), want[::-1, :, :3])
 
 
+def test_harness_json_metrics(tmp_path):
+    """--json 1: one JSON object per frame on stdout (SURVEY section 5's metrics line) and nothing else."""
+    import json
+    out = str(tmp_path / "m.ppm")
+    res = subprocess.run([MAIN, "--scene", "three", "--width", "64", "--height", "36", "--spp", "2", "--frames", "3", "--json", "1",
+                          "--out", out], check=True, capture_output=True, text=True)
+    lines = [json.loads(x) for x in res.stdout.strip().splitlines()]
+    assert [x["frame"] for x in lines] == [0, 1, 2]
+    for x in lines:
+        assert x["width"] == 64 and x["height"] == 36 and x["spp"] == 2 and x["spheres"] == 5 and x["gpus"] == 1
+        assert x["kernel_ms"] > 0 and x["segments"] >= 64 * 36 * 2 and x["mray_per_s_nominal"] > 0
+
+
 def test_library_before_torch_in_one_process():
     """Loading librtiow_hip.so (and creating a context) before torch first touches the GPU must leave one
     HIP runtime in the process: the binding preloads the copy of libamdhip64.so that torch ships."""

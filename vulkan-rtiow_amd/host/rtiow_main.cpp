@@ -5,7 +5,10 @@
 //
 //   rtiow_main --scene cover|cover4096|three|ch05|ch06|file [--file scene.txt] [--width W --height H
 //              --spp S --depth D --seed N --kernel K --frames F --progressive 0|1 --out file.ppm|file.png
-//              --device G | --gpus N | --devices g0,g1,...]
+//              --device G | --gpus N | --devices g0,g1,... --json 0|1]
+//
+// --json 1 prints one JSON object per frame (W, H, spp, depth, spheres, GPUs, kernel and wall ms, nominal Mray/s, segments,
+// sphere tests: the metrics line SURVEY section 5 asks of the harness; the reference logs nothing) instead of the text.
 //
 // --gpus N renders every frame on devices 0..N-1 of this node from this one process (rtCreateMulti: block-cyclic
 // row tiles, one RCCL gather to device 0, de-interleave there); --devices names them (a repeated device is the
@@ -38,7 +41,8 @@ int die(RtContext* ctx, const char* what, int rc) {
 
 int main(int argc, char** argv) {
     std::string scene = "cover", out = "frame.ppm", file;
-    uint32_t width = 1200, height = 800, spp = 100, depth = 50, seed = 1, kernel = 0, frames = 1, progressive = 0;
+    uint32_t width = 1200, height = 800, spp = 100, depth = 50, seed = 1, kernel = 0, frames = 1, progressive = 0, json = 0;
+    uint32_t n_spheres = 1;
     int device = 0;
     std::vector<int> devices;  // --gpus / --devices: the multi-GPU path
     for (int i = 1; i + 1 < argc; i += 2) {
@@ -54,6 +58,7 @@ int main(int argc, char** argv) {
         else if (k == "--kernel") kernel = std::strtoul(v, nullptr, 10);
         else if (k == "--progressive") progressive = std::strtoul(v, nullptr, 10);
         else if (k == "--file") file = v;
+        else if (k == "--json") json = std::strtoul(v, nullptr, 10);
         else if (k == "--frames") frames = std::strtoul(v, nullptr, 10);
         else if (k == "--device") device = std::atoi(v);
         else if (k == "--gpus") { devices.clear(); for (int g = 0; g < std::atoi(v); ++g) devices.push_back(g); }
@@ -72,7 +77,7 @@ int main(int argc, char** argv) {
     if (!devices.empty()) {
         rc = rtCreateMulti(devices.data(), static_cast<int>(devices.size()), &multi);
         if (rc != RT_OK) { std::fprintf(stderr, "rtCreateMulti failed (%d): %s\n", rc, rtMultiGetLastError(nullptr)); return 1; }
-        std::printf("%d devices, transport %s\n", rtMultiDeviceCount(multi), rtMultiTransport(multi));
+        if (!json) std::printf("%d devices, transport %s\n", rtMultiDeviceCount(multi), rtMultiTransport(multi));
     } else {
         rc = rtCreate(device, &ctx);
         if (rc != RT_OK) return die(nullptr, "rtCreate", rc);
@@ -117,7 +122,8 @@ int main(int argc, char** argv) {
         if (multi) {
             if ((rc = rtMultiSetScene(multi, sph.data(), mat.data(), n)) != RT_OK) return die_multi("rtMultiSetScene", rc);
         } else if ((rc = rtSetScene(ctx, sph.data(), mat.data(), n)) != RT_OK) return die(ctx, "rtSetScene", rc);
-        std::printf("scene %s: %u spheres\n", scene.c_str(), n);
+        n_spheres = n;
+        if (!json) std::printf("scene %s: %u spheres\n", scene.c_str(), n);
     }
 
     std::vector<uint8_t> frame(size_t(width) * height * 4);
@@ -141,7 +147,7 @@ int main(int argc, char** argv) {
             RtStats part{};
             for (int g = 0; g < rtMultiDeviceCount(multi); ++g) {
                 if ((rc = rtMultiGetStats(multi, g, &part, &frame_ms)) != RT_OK) return die_multi("rtMultiGetStats", rc);
-                std::printf("  device %d: tile kernel %.3f ms, %u rows\n", devices[g], part.kernel_ms, part.rows_rendered);
+                if (!json) std::printf("  device %d: tile kernel %.3f ms, %u rows\n", devices[g], part.kernel_ms, part.rows_rendered);
                 st.segments += part.segments;
                 st.sphere_tests += part.sphere_tests;
             }
@@ -150,15 +156,23 @@ int main(int argc, char** argv) {
             rtGetStats(ctx, &st);
         }
         const double nominal = double(width) * height * (prm.mode == RT_MODE_PATH ? double(spp) * depth : 1.0);
-        std::printf("frame %u: kernel %.3f ms, wall %.3f ms, %.1f Mray/s nominal, %llu segments, %llu sphere tests\n",
-                    f, st.kernel_ms, wall, nominal / (st.kernel_ms * 1e-3) / 1e6,
-                    (unsigned long long)st.segments, (unsigned long long)st.sphere_tests);
+        if (json)
+            std::printf("{\"frame\": %u, \"scene\": \"%s\", \"width\": %u, \"height\": %u, \"spp\": %u, \"max_depth\": %u, "
+                        "\"spheres\": %u, \"gpus\": %d, \"kernel_ms\": %.4f, \"wall_ms\": %.4f, \"mray_per_s_nominal\": %.1f, "
+                        "\"segments\": %llu, \"sphere_tests\": %llu}\n",
+                        f, scene.c_str(), width, height, prm.mode == RT_MODE_PATH ? spp : 1u, prm.mode == RT_MODE_PATH ? depth : 1u,
+                        n_spheres, multi ? rtMultiDeviceCount(multi) : 1, st.kernel_ms, wall, nominal / (st.kernel_ms * 1e-3) / 1e6,
+                        (unsigned long long)st.segments, (unsigned long long)st.sphere_tests);
+        else
+            std::printf("frame %u: kernel %.3f ms, wall %.3f ms, %.1f Mray/s nominal, %llu segments, %llu sphere tests\n",
+                        f, st.kernel_ms, wall, nominal / (st.kernel_ms * 1e-3) / 1e6,
+                        (unsigned long long)st.segments, (unsigned long long)st.sphere_tests);
     }
     const bool png = out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0;
     rc = png ? rtWritePNG(out.c_str(), frame.data(), width, height, size_t(width) * 4)
              : rtWritePPM(out.c_str(), frame.data(), width, height, size_t(width) * 4);
     if (rc != RT_OK) { rtDestroyMulti(multi); return die(ctx, png ? "rtWritePNG" : "rtWritePPM", rc); }
-    std::printf("wrote %s\n", out.c_str());
+    if (!json) std::printf("wrote %s\n", out.c_str());
     rtDestroy(ctx);
     rtDestroyMulti(multi);
     return 0;
