@@ -200,7 +200,8 @@ int rtSelfTestArith(RtContext* ctx, uint32_t op, const float* a, const float* b,
  * the rows r with (r / row_block) % n == g into its own HBM (RtParams.row_block, 0 = 4); the finished
  * rows are gathered to the root over xGMI (one ncclGather per device in one RCCL group; librccl.so.1 is
  * opened here, not at library load) and one kernel there puts every row in its place.  The frame is the
- * single-GPU frame byte for byte.  n == 1 is rtRender itself.  A list that names one device more than
+ * single-GPU frame byte for byte.  n == 1 is rtRender itself (RTIOW_MULTI_TRANSPORT=rccl: through a one-rank
+ * communicator instead, which exercises the RCCL bindings on a one-GPU box).  A list that names one device more than
  * once (a rehearsal of the n-tile path on fewer GPUs) or RTIOW_MULTI_TRANSPORT=peer moves the tiles with
  * hipMemcpyPeerAsync instead; there is no fallback when RCCL is asked for and fails. */
 typedef struct RtMulti RtMulti;

@@ -102,3 +102,23 @@ def test_harness_gpus_flag(oracle, tmp_path):
         _, dims, _, body = data.split(b"\n", 3)
         img = np.frombuffer(body, np.uint8).reshape(h, w, 3)
         assert np.array_equal(img, want[::-1, :, :3])
+
+
+def test_rccl_bindings_with_a_communicator_of_one(oracle, tmp_path):
+    """RTIOW_MULTI_TRANSPORT=rccl with one device: librccl.so.1 is opened, ncclCommInitAll makes a one-rank communicator
+    and every frame goes through ncclGroupStart / ncclGather (in place) / ncclGroupEnd and the de-interleave kernel.
+    What this box cannot exercise is a transfer between two GPUs; the entry points, their signatures and the call
+    sequence it can.  Run in the C++ harness (a process of its own, no second RCCL from torch in it)."""
+    w, h = 120, 80
+    sph, mat = V.make_cover_scene(1, 11)
+    cam = oracle.make_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, w / h, 0.1, 10.0)
+    want, _ = oracle.render(sph, mat, cam, V.make_params(w, h, spp=3, max_depth=50, seed=1))
+    out = str(tmp_path / "rccl1.ppm")
+    env = dict(os.environ, RTIOW_MULTI_TRANSPORT="rccl")
+    res = subprocess.run([MAIN, "--scene", "cover", "--width", str(w), "--height", str(h), "--spp", "3", "--gpus", "1",
+                          "--frames", "3", "--out", out], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-1500:])
+    assert "transport rccl" in res.stdout
+    _, dims, _, body = open(out, "rb").read().split(b"\n", 3)
+    assert np.array_equal(np.frombuffer(body, np.uint8).reshape(h, w, 3), want[::-1, :, :3])
+

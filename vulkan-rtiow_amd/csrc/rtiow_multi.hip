@@ -14,6 +14,8 @@
 //              or a call fails, rtCreateMulti / rtMultiRender FAIL: there is no silent fallback.
 //   peer-copy  hipMemcpyPeerAsync per tile + events; chosen by RTIOW_MULTI_TRANSPORT=peer, and whenever the list
 //              names one device more than once (a rehearsal of the N-tile path on fewer GPUs, which RCCL refuses).
+//   single     one device: rtRender itself (RTIOW_MULTI_TRANSPORT=rccl runs the rccl transport with a communicator of
+//              one rank instead: the bindings, the group call and the de-interleave on a one-GPU box).
 //   host       plain memcpy between host buffers: rtMultiSelfTestHost, the CPU test of partition, padding and
 //              de-interleave against a host-memory stand-in for the communicator.
 #include <hip/hip_runtime.h>
@@ -240,10 +242,13 @@ int rtCreateMulti(const int* device_ids, int n_devices, RtMulti** out) {
         rtDestroyMulti(m);
         return mfail(nullptr, RT_ERR_HIP, "rtCreateMulti: " + why);
     }
-    if (n == 1) {
+    const char* want = getenv("RTIOW_MULTI_TRANSPORT");
+    // One device is rtRender itself -- unless RTIOW_MULTI_TRANSPORT=rccl asks for the whole N-device machinery with a
+    // communicator of one rank: librccl is opened, ncclCommInitAll, the grouped ncclGather (in place: nothing moves)
+    // and the de-interleave all run.  That is how the RCCL bindings are exercised on a one-GPU box.
+    if (n == 1 && !(want && std::strcmp(want, "rccl") == 0)) {
         m->transport = Transport::kSingle;
     } else {
-        const char* want = getenv("RTIOW_MULTI_TRANSPORT");
         const bool peer = !distinct || (want && std::strcmp(want, "peer") == 0);
         if (peer) {
             m->transport = Transport::kPeerCopy;
@@ -295,7 +300,7 @@ int rtMultiRender(RtMulti* m, const RtCamera* cam, const RtParams* params, void*
     const uint32_t n = static_cast<uint32_t>(m->ctx.size());
     const int root = m->devices[0];
     m->have_timing = false;
-    if (n == 1) {  // degenerate: the single-GPU path, untouched
+    if (m->transport == Transport::kSingle) {  // one device: the single-GPU path, untouched
         const int rc = rtRender(m->ctx[0], cam, params, dst, dst_pitch, dst_is_device, nullptr);
         if (rc != RT_OK) return mfail(m, rc, std::string("rtMultiRender: ") + rtGetLastError(m->ctx[0]));
         return RT_OK;
