@@ -122,3 +122,32 @@ def test_rccl_bindings_with_a_communicator_of_one(oracle, tmp_path):
     _, dims, _, body = open(out, "rb").read().split(b"\n", 3)
     assert np.array_equal(np.frombuffer(body, np.uint8).reshape(h, w, 3), want[::-1, :, :3])
 
+
+
+def test_torch_rccl_backend_with_one_rank():
+    """bench.py's N > 1 calls on the `nccl` (= RCCL) backend with a world of one rank: process-group init with a device
+    id, the rooted gather into views of one receive buffer exactly as dist.gather_frame issues it, the all-gather form,
+    the all_reduce of the timing tensor, barrier, teardown.  A second rank needs a second GPU; the API usage does not."""
+    import sys
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "from importlib import import_module\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29544')\n"
+        "dev = torch.device('cuda', 0); torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)\n"
+        "D = import_module('vulkan-rtiow_amd.dist')\n"
+        "h, w, block = 37, 19, 4\n"
+        "local = torch.arange(h * w, dtype=torch.int32, device=dev).reshape(h, w)\n"
+        "side = torch.cuda.Stream()\n"
+        "with torch.cuda.stream(side):\n"
+        "    recv = torch.empty((1, h, w), dtype=torch.int32, device=dev)\n"
+        "    dist.gather(local, gather_list=list(recv.unbind(0)), dst=0)\n"
+        "    frame = D._deinterleave(recv, h, block, 1)\n"
+        "    recv2 = torch.empty((1, h, w), dtype=torch.int32, device=dev)\n"
+        "    dist.all_gather_into_tensor(recv2.view(h, w), local)\n"
+        "t = torch.tensor([1.5, 2.5], dtype=torch.float64, device=dev)\n"
+        "dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier(); torch.cuda.synchronize()\n"
+        "assert torch.equal(frame, local) and torch.equal(recv2[0], local) and t.tolist() == [1.5, 2.5]\n"
+        "dist.destroy_process_group(); print('rccl-one-rank ok')\n")
+    res = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "rccl-one-rank ok" in res.stdout, res.stderr[-3000:]
