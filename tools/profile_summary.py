@@ -64,6 +64,16 @@ for k, v in pmc.items():  # derived: share of the 64 lanes active in an average 
     if isinstance(v, dict) and "SQ_THREAD_CYCLES_VALU" in v and "SQ_ACTIVE_INST_VALU" in v:
         v["lane_occupancy_valu"] = v["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"] / (64.0 * max(1.0, v["SQ_ACTIVE_INST_VALU"]["mean_per_launch"]))
 json.dump(pmc, open(os.path.join(prof, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+# per-launch durations of the path kernel (the stats csv averages the warm-up launch in: cold caches, natural chunk order)
+kt = one(f"prof_{tag}_stats/**/*_kernel_trace.csv")
+if kt:
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(kt))
+         if "path_persistent" in r["Kernel_Name"]]
+    warm = int(((bench_line or {}).get("warmup")) or 0)
+    timed = d[warm:] if len(d) > warm else d
+    json.dump({"path_kernel_ms_per_launch": d, "warmup_launches": warm, "mean_ms_of_timed_launches": sum(timed) / max(1, len(timed)),
+               "bench_event_ms_same_run": (bench_line or {}).get("config", {}).get("kernel_ms_rank0")},
+              open(os.path.join(prof, f"{tag}_kernel_launches.json"), "w"), indent=1)
 chs = one(f"prof_{tag}_ch/**/*_kernel_stats.csv")
 if chs:
     shutil.copy(chs, os.path.join(prof, f"{tag}_ch_kernel_stats.csv"))
