@@ -205,3 +205,15 @@ def test_path_blue_white_hall_known_answer(oracle):
     cam = oracle.make_camera((0, 0.3, 0.6), (0, 0, -1.6), (0, 1, 0), 55.0, w / h, 0.0, 1.0)
     img, _ = oracle.render(sph, mat, cam, V.make_params(w, h, spp=16, max_depth=furnace.WHITE_HALL_DEPTH, seed=7))
     furnace.check_white_hall(img)
+
+
+def test_path_glass_ball_known_answer(oracle):
+    """Fifth analytic pin (tests/glass.py): the expected colour of a glass ball under the gradient sky, summed in float64
+    over the tree of reflect/refract choices and the pixel footprint -- pins Snell, Schlick, the normal flip and the
+    choice probabilities by their effect on DIRECTION, which the head-on and furnace pins cannot see."""
+    import glass
+    w, h = 96, 64
+    sph, mat = glass.scene()
+    img, _ = oracle.render(sph, mat, glass.camera(w, h), V.make_params(w, h, spp=2048, max_depth=50, seed=3))
+    assert glass.check(img, w, h, tol=3) <= 3
+
