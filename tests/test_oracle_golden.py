@@ -217,3 +217,14 @@ def test_path_glass_ball_known_answer(oracle):
     img, _ = oracle.render(sph, mat, glass.camera(w, h), V.make_params(w, h, spp=2048, max_depth=50, seed=3))
     assert glass.check(img, w, h, tol=3) <= 3
 
+
+def test_path_lambertian_ball_known_answer(oracle):
+    """Sixth analytic pin (tests/lambert.py): a lone diffuse ball under the gradient sky has the closed form
+    albedo * sky(2/3 n.y) -- cosine-weighted scattering has mean direction 2/3 n and the sky is linear in y.  Pins the
+    distribution of the spec's rejection-free unit-vector sampling."""
+    import lambert
+    w, h = 96, 64
+    sph, mat = lambert.scene()
+    img, _ = oracle.render(sph, mat, lambert.camera(w, h), V.make_params(w, h, spp=2048, max_depth=50, seed=5))
+    assert lambert.check(img, w, h, tol=3) <= 3
+
