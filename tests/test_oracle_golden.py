@@ -228,3 +228,13 @@ def test_path_lambertian_ball_known_answer(oracle):
     img, _ = oracle.render(sph, mat, lambert.camera(w, h), V.make_params(w, h, spp=2048, max_depth=50, seed=5))
     assert lambert.check(img, w, h, tol=3) <= 3
 
+
+def test_path_fuzzy_metal_ball_known_answer(oracle):
+    """Seventh analytic pin (tests/fuzzmetal.py): a lone metal ball with fuzz 0.6 -- the expectation is a 2-D integral over
+    the fuzz vector (float64 midpoint rule), absorption of directions that point into the surface included."""
+    import fuzzmetal
+    w, h = 96, 64
+    sph, mat = fuzzmetal.scene()
+    img, _ = oracle.render(sph, mat, fuzzmetal.camera(w, h), V.make_params(w, h, spp=2048, max_depth=50, seed=5))
+    assert fuzzmetal.check(img, w, h, tol=3) <= 3
+
