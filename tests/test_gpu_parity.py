@@ -303,6 +303,18 @@ def test_path_fuzzy_metal_ball_known_answer_on_gpu(gpu_ctx, kernel):
     assert fuzzmetal.check(img, w, h, tol=3) <= 3
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_path_defocused_mirror_ball_known_answer_on_gpu(gpu_ctx, kernel):
+    """Eighth analytic pin (tests/defocus.py), no oracle in the loop: the thin-lens camera (lens disk sampled by area,
+    origin and direction shifted by the lens offset) against a float64 integral, every PATH kernel, within 3 bytes."""
+    import defocus
+    w, h = 96, 64
+    sph, mat = defocus.scene()
+    gpu_ctx.set_scene(sph, mat)
+    img = gpu_ctx.render(defocus.camera(w, h), V.make_params(w, h, spp=2048, max_depth=50, seed=5, kernel=kernel))
+    assert defocus.check(img, w, h, tol=3) <= 3
+
+
 def test_ch05_stretched_reference_jpeg_on_gpu(gpu_ctx):
     """RTCHAP05/RTCHAP05/1728.jpg straight against the HIP kernel (no oracle): UBO {1024, 1024, 2, 2, 1}, flipped
     and sampled at the 800x600 window's pixel centres; same bounds as the oracle's test of this fixture."""

@@ -238,3 +238,14 @@ def test_path_fuzzy_metal_ball_known_answer(oracle):
     img, _ = oracle.render(sph, mat, fuzzmetal.camera(w, h), V.make_params(w, h, spp=2048, max_depth=50, seed=5))
     assert fuzzmetal.check(img, w, h, tol=3) <= 3
 
+
+def test_path_defocused_mirror_ball_known_answer(oracle):
+    """Eighth analytic pin (tests/defocus.py): the thin-lens camera.  A mirror ball well out of focus; the expectation is an
+    integral over pixel footprint x lens disk (float64, own restatement of the book's camera).  A lens sampled uniformly
+    in radius instead of area would be off by 5 bytes."""
+    import defocus
+    w, h = 96, 64
+    sph, mat = defocus.scene()
+    img, _ = oracle.render(sph, mat, defocus.camera(w, h), V.make_params(w, h, spp=2048, max_depth=50, seed=5))
+    assert defocus.check(img, w, h, tol=3) <= 3
+
