@@ -12,18 +12,23 @@
  *    statement (RTCHAP05/RTCHAP05/Shaders/raytrace05.comp:21-61 and
  *    RTCHAP06/Shaders/raytrace06.comp:21-66), with the UBO of
  *    RTCHAP06/main.cpp:101-120 and the display flip of RTCHAP06/Shaders/rt.frag:8.
- *    They are pinned against the only result fixture the reference holds,
+ *    They are pinned against the three result fixtures the reference holds --
  *    RTCHAP05/RTCHAP05/21986.jpg (silhouette bbox, hit count 167 084, corner
- *    colours), through the known-answer table of SURVEY.md section 8(c) committed
- *    under tests/golden/.  The GLSL cannot be compiled here (no glslc, Vulkan
+ *    colours), RTCHAP05/RTCHAP05/1728.jpg (the stretched 1024^2 image: ellipse
+ *    bbox) and RT01/RT01/4068.jpg (sky) -- through tests/golden/ and the
+ *    known-answer table of SURVEY.md section 8(c).  The GLSL cannot be compiled here (no glslc, Vulkan
  *    loader or ICD in the image), so "pinned by source text + that fixture".
  *  * RT_MODE_PATH (hittable list, lambertian/metal/dielectric, multi-sample
  *    accumulate, cover scene) DOES NOT EXIST in the reference (SURVEY.md
  *    section 0.1).  It follows the public RTIOW book as recorded in SURVEY.md
  *    section 9; this file is its authority.  PARITY UNPINNED for this mode.
- *    (What can be checked without the reference is checked analytically:
- *    tests/furnace.py, a known answer that follows from raytrace06.comp:45-47's
- *    sky alone, holds for this file and for every GPU kernel.)
+ *    (What can be checked without the reference is checked analytically, by
+ *    computations that share nothing with this file and hold for it and for
+ *    every GPU kernel: tests/furnace.py (single bodies, head-on rays, a hall of
+ *    non-absorbing bodies with hollow glass), tests/mirrors.py (reflection chains
+ *    among several spheres), tests/glass.py (refraction directions and Schlick
+ *    probabilities), tests/lambert.py (the diffuse distribution),
+ *    tests/fuzzmetal.py (fuzz and absorption), tests/defocus.py (the thin lens).)
  *
  * Arithmetic contract (shared with the HIP kernels, which are written
  * independently of this file): IEEE-754 binary32, round-to-nearest-even,
