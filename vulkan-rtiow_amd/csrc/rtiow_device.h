@@ -18,7 +18,9 @@ struct alignas(128) QueueHead {
 };
 
 struct Counters {
-    QueueHead xcd_head[8];          // persistent kernel: heads of the eight per-XCD pixel queues
+    QueueHead xcd_head[8];          // persistent kernel: heads of the eight per-XCD pixel queues (their last part, handed
+                                    // out in pools of a few pixels, counted from where the whole chunks end)
+    QueueHead xcd_chunk[8];         // ... and of their first part, handed out in whole chunks: one atomic per fetch, no look
     unsigned long long paths;
     unsigned long long segments;
     unsigned long long tests;       // ray-sphere and ray-bound tests performed

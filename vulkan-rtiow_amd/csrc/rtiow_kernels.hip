@@ -1351,6 +1351,10 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     // then (SHADE_LDS) two float4 of shading record per sphere; then the accumulator entries of every
     // wave of the workgroup (a wave allocates only from its own 64).
     extern __shared__ float4 lds_spheres[];
+    __shared__ unsigned long long wg_sums[3];  // paths, segments, tests of the waves that have left
+    __shared__ unsigned int wg_left;           // how many have
+    if (threadIdx.x < 3u) wg_sums[threadIdx.x] = 0ull;
+    if (threadIdx.x == 3u) wg_left = 0u;
     uint32_t* lds_cidx = reinterpret_cast<uint32_t*>(lds_spheres + g.n_pad);
     float4* lds_cbounds = reinterpret_cast<float4*>(lds_cidx + (ACCEL ? g.n_pad : 0u));
     float4* lds_shade = lds_cbounds + (ACCEL ? 2u * (a.n_clusters + a.n_super) : 0u);
@@ -1399,6 +1403,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     uint32_t cur_s = a.spp;                  // its next sample; == spp: no pixel open
     unsigned long long free_entries = ~0ull; // accumulator entries not in use
     uint32_t free_lines = (1u << kLineBufs) - 1u;  // line buffers not in use
+    uint32_t whole_done = 0u;                // bit q: the whole-chunk part of queue q is known to be handed out
     bool pool_owned = false;                 // the pool is whole chunks of the frame that only this wave renders
     uint32_t cur_line = 0u;                  // line buffer of the chunk being handed out, + 1 (0: its pixels go straight to the frame)
     [[maybe_unused]] bool exhausted = false; // the global queue has been drained
@@ -1433,48 +1438,69 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             while (served < want) {  // one trip per pixel touched (1-2 unless spp is tiny)
                 if (cur_s == a.spp) {  // open the next pixel of the pool
                     if (pool_next == pool_end) {
-                        // Pool fetch: one atomic per wave per pool.  The tile's pixels are cut into chunks
-                        // of kChunkPix consecutive pixels dealt round-robin to eight queues, one per XCD:
-                        // a wave draws from the queue of the XCD it runs on, so the 4-byte stores that
-                        // complete a 128-byte line of the frame all come from one L2 and merge there.
-                        // An XCD whose queue is dry steals from the next one.  Pool size is guided from
-                        // the CURRENT head (a stale one would let a wave grab a full pool at the very end).
+                        // Pool fetch.  The tile's pixels are cut into chunks of kChunkPix consecutive pixels dealt
+                        // round-robin to eight queues, one per XCD: a wave draws from the queue of the XCD it runs
+                        // on, so the 4-byte stores that complete a 128-byte line of the frame all come from one L2
+                        // and merge there.  An XCD whose queue is dry steals from the next one.
                         bool fetched = false;
                         while (steal < 8u && !fetched) {
                             const uint32_t xq = (xcc + steal) & 7u;
                             const uint32_t vsize = ((n_chunks + 7u - xq) / 8u) * kChunkPix;  // virtual pixels of queue xq
+                            // Its first part -- all but the last g.chunk_until pixels -- is handed out in WHOLE chunks (32 pixels
+                            // = one 128-byte line of the frame): the wave renders every pixel of the line itself, assembles it in
+                            // LDS and writes it with one store.  That part has a head of its own and a fetch is one atomic add, no
+                            // look at the head first (a look and an add are 64 bytes of fabric traffic each: with one queue for
+                            // everything the looks alone were 1.9 MB per cover frame, half of what the frame itself weighs).
+                            const uint32_t wsize = vsize > g.chunk_until ? (vsize - g.chunk_until) / g.chunk_pool * g.chunk_pool : 0u;
+                            if (wsize != 0u && ((whole_done >> xq) & 1u) == 0u) {
+                                uint32_t got = 0u;
+                                if (lane == 0u) got = atomicAdd(&a.counters->xcd_chunk[xq].next, g.chunk_pool);
+                                got = __builtin_amdgcn_readfirstlane(got);
+                                if (got < wsize) {
+                                    pool_next = got;
+                                    pool_end = got + g.chunk_pool;  // (<= wsize: both are multiples of the pool)
+                                    pool_xcd = xq;
+                                    pool_owned = true;
+                                    fetched = true;
+#ifdef RTIOW_DEBUG_TIMELINE
+                                    if (xq == 0u && lane == 0u && got * 8u / vsize != (got + g.chunk_pool) * 8u / vsize) {
+                                        const unsigned long long t0w = ~__hip_atomic_load(&a.counters->not_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        a.counters->tl_progress[(got + g.chunk_pool) * 8u / vsize] = static_cast<unsigned int>(wall_clock64() - t0w);
+                                    }
+#endif
+                                    break;
+                                }
+                                whole_done |= 1u << xq;  // (heads only grow)
+                            }
+                            // The rest of the queue -- by then every wave still holds half a chunk on average, which this part
+                            // has to balance -- goes in pools of a few pixels, each pixel stored when it completes.  Pool size is
+                            // guided from the CURRENT head (a stale one would let a wave grab a full pool at the very end).
+                            const uint32_t rest = vsize - wsize;
                             uint32_t head_now = 0u;
                             if (lane == 0u)
                                 head_now = __hip_atomic_load(&a.counters->xcd_head[xq].next, __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_AGENT);
                             head_now = __builtin_amdgcn_readfirstlane(head_now);
-                            if (head_now < vsize) {
+                            if (head_now < rest) {
 #ifndef RTIOW_GUIDE_DIV
 #define RTIOW_GUIDE_DIV 4u
 #endif
-                                uint32_t k = (vsize - head_now) / (g.total_waves / RTIOW_GUIDE_DIV + 1u);  // ~waves per XCD x 2
+                                uint32_t k = (rest - head_now) / (g.total_waves / RTIOW_GUIDE_DIV + 1u);  // ~waves per XCD x 2
                                 k = k < 1u ? 1u : (k > g.pool_pix ? g.pool_pix : k);
-                                // Far from the end of the queue a wave takes WHOLE chunks (32 pixels = one 128-byte line of
-                                // the frame): it renders every pixel of the line itself, assembles it in LDS and writes it
-                                // with one store.  Near the end (by then every wave still holds half a chunk on average,
-                                // which the rest of the queue has to balance) pools are a few pixels, stored one by one.
-                                const bool whole = vsize - head_now >= g.chunk_until;
-                                if (whole) k = g.chunk_pool;
                                 uint32_t got = 0u;
                                 if (lane == 0u) got = atomicAdd(&a.counters->xcd_head[xq].next, k);
                                 got = __builtin_amdgcn_readfirstlane(got);
 #ifdef RTIOW_DEBUG_TIMELINE
-                                if (xq == 0u && lane == 0u && got < vsize && got * 8u / vsize != (got + k) * 8u / vsize) {
+                                if (xq == 0u && lane == 0u && got < rest && (wsize + got) * 8u / vsize != (wsize + got + k) * 8u / vsize) {
                                     const unsigned long long t0w = ~__hip_atomic_load(&a.counters->not_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    a.counters->tl_progress[(got + k) * 8u / vsize] = static_cast<unsigned int>(wall_clock64() - t0w);
+                                    a.counters->tl_progress[(wsize + got + k) * 8u / vsize] = static_cast<unsigned int>(wall_clock64() - t0w);
                                 }
 #endif
-                                if (got < vsize) {
-                                    pool_next = got;
-                                    pool_end = vsize - got < k ? vsize : got + k;
+                                if (got < rest) {
+                                    pool_next = wsize + got;
+                                    pool_end = rest - got < k ? vsize : wsize + got + k;
                                     pool_xcd = xq;
-                                    // (a pool of few pixels may have slipped in between the look at the head and the add)
-                                    pool_owned = whole && got % kChunkPix == 0u && got + k <= vsize;
+                                    pool_owned = false;
                                     fetched = true;
                                     break;
                                 }
@@ -1805,7 +1831,9 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         }
     }
 #endif
-    // one counter update per wave
+    // One counter update per WORKGROUP: the waves sum in LDS as they leave, the last one out adds the sums to the global
+    // counters (a global atomic is a 64-byte memory-side request: three per wave were 0.6 MB per frame).  A wave's sums
+    // reach LDS before its arrival tick (its LDS operations are performed in order), so the last arrival sees them all.
     unsigned long long tests64 = n_tests;
     for (int off = 32; off > 0; off >>= 1) {
         n_paths += __shfl_down(n_paths, off);
@@ -1813,9 +1841,14 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         tests64 += __shfl_down(tests64, off);
     }
     if (lane == 0u) {
-        atomicAdd(&a.counters->paths, static_cast<unsigned long long>(n_paths));
-        atomicAdd(&a.counters->segments, static_cast<unsigned long long>(n_segments));
-        atomicAdd(&a.counters->tests, tests64);
+        atomicAdd(&wg_sums[0], static_cast<unsigned long long>(n_paths));
+        atomicAdd(&wg_sums[1], static_cast<unsigned long long>(n_segments));
+        atomicAdd(&wg_sums[2], tests64);
+        if (atomicAdd(&wg_left, 1u) + 1u == waves_in_group) {
+            atomicAdd(&a.counters->paths, wg_sums[0]);
+            atomicAdd(&a.counters->segments, wg_sums[1]);
+            atomicAdd(&a.counters->tests, wg_sums[2]);
+        }
     }
 #ifdef RTIOW_DEBUG_COUNTERS
     // debug[0] wave-level slow-loop trips, [1] lane-level candidates, [2] wave iterations
@@ -1997,7 +2030,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // default: the clustered list from kClusteredFrom spheres on (cover scene: 2.1x faster than the
     // flat list; frames are byte-identical either way), the flat list for the handful-of-spheres scenes
     bool accel = kernel == KERNEL_CLUSTERED || (kernel == KERNEL_DEFAULT && a.n >= kClusteredFrom);
-    constexpr size_t kLdsPerCu = 160u * 1024u;
+    constexpr size_t kLdsPerCu = 160u * 1024u - 64u;  // (the kernel's few static __shared__ words come on top of the dynamic part)
     // The clustered list must fit the LDS beside four waves' buffers.  The very largest scenes give up
     // the super-cluster level first (its boxes and second work list), then fall back to the flat list.
     auto clustered_fits = [&](uint32_t n_super) {
