@@ -151,3 +151,19 @@ def test_torch_rccl_backend_with_one_rank():
         "dist.destroy_process_group(); print('rccl-one-rank ok')\n")
     res = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "rccl-one-rank ok" in res.stdout, res.stderr[-3000:]
+
+
+def test_multi_progressive_accumulation(oracle):
+    """The frame loop with a running average on N tiles: every device keeps the accumulators of its own rows, k dispatches
+    of spp samples are one dispatch of k * spp, and every intermediate frame is the oracle's at that sample count."""
+    w, h = 131, 70
+    sph, mat, cam = _case(oracle, "cover11", w, h)
+    with V.MultiContext([0, 0, 0]) as m:
+        m.set_scene(sph, mat)
+        done = 0
+        for spp in (2, 3, 1):
+            prm = V.make_params(w, h, spp=spp, max_depth=50, seed=9, row_block=4, sample_offset=done, accumulate=1)
+            got = m.render(cam, prm)
+            done += spp
+            want, _ = oracle.render(sph, mat, cam, V.make_params(w, h, spp=done, max_depth=50, seed=9))
+            assert np.array_equal(got, want), done
