@@ -1404,6 +1404,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     unsigned long long free_entries = ~0ull; // accumulator entries not in use
     uint32_t free_lines = (1u << kLineBufs) - 1u;  // line buffers not in use
     uint32_t whole_done = 0u;                // bit q: the whole-chunk part of queue q is known to be handed out
+    uint32_t rest_done = 0u;                 // ... and the rest of it
     bool pool_owned = false;                 // the pool is whole chunks of the frame that only this wave renders
     uint32_t cur_line = 0u;                  // line buffer of the chunk being handed out, + 1 (0: its pixels go straight to the frame)
     [[maybe_unused]] bool exhausted = false; // the global queue has been drained
@@ -1473,20 +1474,14 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                                 whole_done |= 1u << xq;  // (heads only grow)
                             }
                             // The rest of the queue -- by then every wave still holds half a chunk on average, which this part
-                            // has to balance -- goes in pools of a few pixels, each pixel stored when it completes.  Pool size is
-                            // guided from the CURRENT head (a stale one would let a wave grab a full pool at the very end).
+                            // has to balance -- goes in pools of a few pixels, each pixel stored when it completes.  One atomic
+                            // add per pool here too.  (Round 1 looked at the head first and shrank the pools towards the end of
+                            // the queue -- "guided" sizes.  Pools are at most a handful of pixels anyway: with the shrinking
+                            // switched off the cover frame and a 1/8 tile took the same time, and every look is 64 bytes of fabric
+                            // traffic, 1.3 MB per frame.)
                             const uint32_t rest = vsize - wsize;
-                            uint32_t head_now = 0u;
-                            if (lane == 0u)
-                                head_now = __hip_atomic_load(&a.counters->xcd_head[xq].next, __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT);
-                            head_now = __builtin_amdgcn_readfirstlane(head_now);
-                            if (head_now < rest) {
-#ifndef RTIOW_GUIDE_DIV
-#define RTIOW_GUIDE_DIV 4u
-#endif
-                                uint32_t k = (rest - head_now) / (g.total_waves / RTIOW_GUIDE_DIV + 1u);  // ~waves per XCD x 2
-                                k = k < 1u ? 1u : (k > g.pool_pix ? g.pool_pix : k);
+                            if (((rest_done >> xq) & 1u) == 0u) {
+                                const uint32_t k = g.pool_pix;
                                 uint32_t got = 0u;
                                 if (lane == 0u) got = atomicAdd(&a.counters->xcd_head[xq].next, k);
                                 got = __builtin_amdgcn_readfirstlane(got);
@@ -1504,6 +1499,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                                     fetched = true;
                                     break;
                                 }
+                                rest_done |= 1u << xq;
                             }
                             ++steal;  // this queue is dry for good: heads only grow
                         }
