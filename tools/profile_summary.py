@@ -41,8 +41,13 @@ for kind in ("fetch", "write", "sq", "lds", "lane"):
         if "path_persistent" in name:
             pmc.setdefault("_dispatch_" + name, {"vgpr": r["VGPR_Count"], "sgpr": r["SGPR_Count"], "lds": r["LDS_Block_Size"],
                                          "scratch": r["Scratch_Size"], "grid": r["Grid_Size"], "wg": r["Workgroup_Size"]})
+    warm = int(((bench_line or {}).get("warmup")) or 0)
     for (name, ctr), vals in agg.items():
-        pmc.setdefault(name, {})[ctr] = {"mean_per_launch": sum(vals) / len(vals), "launches": len(vals)}
+        # the path kernel's warm-up launches (cold caches, natural chunk order, cost reports per pixel) are kept apart:
+        # bench.py's timed region does not contain them either
+        timed = vals[warm:] if name.startswith("path_persistent") and len(vals) > warm else vals
+        pmc.setdefault(name, {})[ctr] = {"mean_per_launch": sum(timed) / len(timed), "launches": len(timed),
+                                         "per_launch_incl_warmup": vals if name.startswith("path_persistent") else None}
 
 traffic = None
 want_accel = (bench_line or {}).get("config", {}).get("kernel") == "persistent_clustered_list"
