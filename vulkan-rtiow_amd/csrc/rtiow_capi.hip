@@ -89,7 +89,7 @@ int rtCreate(int device_id, RtContext** out_ctx) {
         (e = hipEventCreate(&ctx->ev_start)) != hipSuccess ||
         (e = hipEventCreate(&ctx->ev_stop)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), sizeof(rtiow::Counters))) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), 2 * sizeof(rtiow::Counters))) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_counters), sizeof(rtiow::Counters))) != hipSuccess) {
         int rc = fail_hip(nullptr, e, "rtCreate");
         rtDestroy(ctx);
@@ -265,7 +265,10 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
     // the reference's kernels keep no counters: their frame is launch-bound (7 us of kernel), so the
     // counter reset and read-back are left out of its dispatch (16 -> 9 us per frame, tools/ch_dispatch_rate.py)
     ctx->last_is_ch = is_ch;
-    if (!is_ch) RT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(rtiow::Counters), stream));
+    // PATH frames count in one of two counter blocks; a persistent kernel's last workgroup zeroes the other one for the
+    // frame after it, so only the first frame (and one that follows the one-lane-per-pixel kernel) needs a memset
+    rtiow::Counters* counters = ctx->d_counters + ctx->counter_index;
+    if (!is_ch && !ctx->counter_clean) RT_HIP(ctx, hipMemsetAsync(counters, 0, sizeof(rtiow::Counters), stream));
     RT_HIP(ctx, hipEventRecord(ctx->ev_start, stream));
     if (is_ch) {
         rtiow::ChArgs a{};
@@ -314,7 +317,8 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         a.local_rows = rows;
         a.dst = out;
         a.dst_stride = out_stride;
-        a.counters = ctx->d_counters;
+        a.counters = counters;
+        a.next_counters = ctx->d_counters + (ctx->counter_index ^ 1u);
         // The cluster boxes are inflated for ray origins within cluster_range scene diagonals of the
         // scene's centre (rtiow_clusters.cpp); the kernel sends any ray that starts farther out through
         // every cluster.  A camera out there would do that for all its primary rays: the boxes are rebuilt
@@ -382,15 +386,15 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         }
         RT_HIP(ctx, rtiow::launch_path(a, kernel, prm->chunk_spp, ctx->num_cus, stream, &ctx->last_kernel));
         RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream));
+        ctx->stats_index = ctx->counter_index;
+        ctx->counter_index ^= 1u;
+        ctx->counter_clean = ctx->last_kernel != rtiow::KERNEL_PIXEL;  // (that kernel does not reset the other block)
         if (ordered && collect) {
             RT_HIP(ctx, rtiow::launch_order_chunks(ctx->d_chunk_cost, ctx->d_chunk_order, n_chunks, prm->spp, stream));
             ctx->order_valid = true;
         }
     }
     if (is_ch) RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream));
-    if (!is_ch)
-        RT_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(rtiow::Counters),
-                                   hipMemcpyDeviceToHost, stream));
     ctx->have_timing = true;
 
     if (!dst_is_device) {
@@ -474,7 +478,11 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
         float ms = 0.0f;
         RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
         ctx->stats.kernel_ms = ms;
-        if (ctx->last_is_ch) std::memset(ctx->h_counters, 0, sizeof(rtiow::Counters));
+        if (ctx->last_is_ch) {
+            std::memset(ctx->h_counters, 0, sizeof(rtiow::Counters));
+        } else {  // (fetched here, not after every frame: one small copy less between two frames of a loop)
+            RT_HIP(ctx, hipMemcpy(ctx->h_counters, ctx->d_counters + ctx->stats_index, sizeof(rtiow::Counters), hipMemcpyDeviceToHost));
+        }
         ctx->stats.paths = ctx->h_counters->paths;
         ctx->stats.segments = ctx->h_counters->segments;
         // persistent kernels count the tests they perform; the one-lane-per-pixel kernel tests every

@@ -29,7 +29,10 @@ struct RtContext {
     std::vector<RtSphere> host_spheres;  // kept to re-box the clusters for a camera farther out
     double cluster_range = 0;     // range_diags the current boxes were built for
     uint32_t n_spheres = 0;
-    rtiow::Counters* d_counters = nullptr;
+    rtiow::Counters* d_counters = nullptr;  // TWO blocks: frame k counts in block k & 1 and its last workgroup zeroes the other
+    uint32_t counter_index = 0;             // the block the next PATH frame uses ...
+    bool counter_clean = false;             // ... which the previous frame's kernel has already zeroed
+    uint32_t stats_index = 0;               // the block the last PATH frame counted in (read by rtGetStats)
     rtiow::Counters* h_counters = nullptr;  // pinned
     uint32_t* d_frame = nullptr;            // staging framebuffer for host destinations
     size_t frame_bytes = 0;

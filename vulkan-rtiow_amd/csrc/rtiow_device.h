@@ -21,6 +21,8 @@ struct Counters {
     QueueHead xcd_head[8];          // persistent kernel: heads of the eight per-XCD pixel queues (their last part, handed
                                     // out in pools of a few pixels, counted from where the whole chunks end)
     QueueHead xcd_chunk[8];         // ... and of their first part, handed out in whole chunks: one atomic per fetch, no look
+    unsigned int wg_done;           // persistent kernel: workgroups that have left (the last one out resets the OTHER
+    unsigned int pad0;              // counter block for the next frame: no memset between frames)
     unsigned long long paths;
     unsigned long long segments;
     unsigned long long tests;       // ray-sphere and ray-bound tests performed
@@ -84,6 +86,7 @@ struct PathArgs {
     uint32_t* dst;               // local_rows x dst_stride words
     uint32_t dst_stride;         // in 32-bit words
     Counters* counters;
+    Counters* next_counters;     // persistent kernels: the block the NEXT frame will use, zeroed by this frame's last workgroup
     // Cost-ordered dequeue (persistent kernels): the tile's pixels are handed out in chunks of 32; place s of the
     // chunk sequence holds the chunk chunk_order names for it (null: s itself; layout: launch_order_chunks).  Finished
     // pixels add the segments their samples took to chunk_cost[their chunk] (a wave that renders a whole chunk sums

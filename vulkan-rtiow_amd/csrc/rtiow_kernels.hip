@@ -1831,6 +1831,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     // counters (a global atomic is a 64-byte memory-side request: three per wave were 0.6 MB per frame).  A wave's sums
     // reach LDS before its arrival tick (its LDS operations are performed in order), so the last arrival sees them all.
     unsigned long long tests64 = n_tests;
+    bool last_group = false;
     for (int off = 32; off > 0; off >>= 1) {
         n_paths += __shfl_down(n_paths, off);
         n_segments += __shfl_down(n_segments, off);
@@ -1844,7 +1845,16 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             atomicAdd(&a.counters->paths, wg_sums[0]);
             atomicAdd(&a.counters->segments, wg_sums[1]);
             atomicAdd(&a.counters->tests, wg_sums[2]);
+            // the last workgroup out zeroes the counter block of the NEXT frame (queue heads and all): the frames of a
+            // loop then follow each other without a memset in between (with the stats copy moved to rtGetStats, the gap
+            // between two path kernels went from 34 to ~10 us)
+            last_group = atomicAdd(&a.counters->wg_done, 1u) + 1u == gridDim.x;
         }
+    }
+    last_group = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(last_group)) != 0u;
+    if (last_group && a.next_counters != nullptr) {
+        uint32_t* words = reinterpret_cast<uint32_t*>(a.next_counters);
+        for (uint32_t k = lane; k < sizeof(Counters) / 4u; k += 64u) words[k] = 0u;
     }
 #ifdef RTIOW_DEBUG_COUNTERS
     // debug[0] wave-level slow-loop trips, [1] lane-level candidates, [2] wave iterations
