@@ -119,7 +119,10 @@ typedef struct RtParams {
     uint32_t tile_count;
     uint32_t kernel;     /* 0 = default (persistent waves; flat sphere list below 64 spheres, clustered
                             list from 64 on); 1 one lane per pixel; 2 persistent, flat list; 3 persistent,
-                            clustered list.  Frames are identical by contract. */
+                            clustered list; 4 = 3 with the primary pass (camera rays traced where they are
+                            made, against the spheres their pixels' cones reach) at any spp -- 0 and 3 use
+                            it from 16 samples per pixel on; rtGetLastKernel reports 3.  Frames are
+                            identical by contract. */
     /* Progressive accumulation, the frame loop of RTCHAP06/main.cpp:304-360 with a running
      * average: with accumulate != 0 this dispatch adds samples sample_offset .. sample_offset+spp-1
      * of every pixel to accumulators the context keeps (reset when sample_offset == 0) and writes

@@ -11,7 +11,7 @@ import vulkan_rtiow_amd as V
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-KERNELS = [V.KERNEL_PIXEL, V.KERNEL_PERSISTENT, V.KERNEL_CLUSTERED]
+KERNELS = [V.KERNEL_PIXEL, V.KERNEL_PERSISTENT, V.KERNEL_CLUSTERED, V.KERNEL_CLUSTERED_PASS]
 
 
 def _diff(a, b):
@@ -130,7 +130,7 @@ def test_path_bit_exact_vs_oracle(gpu_ctx, oracle, kernel, scene, w, h, spp, dep
     assert np.array_equal(got, want), _diff(got, want)   # stronger than the L_inf <= 1/255 bar
     st = gpu_ctx.stats()
     assert st.segments == segs
-    if kernel != V.KERNEL_CLUSTERED:
+    if kernel not in (V.KERNEL_CLUSTERED, V.KERNEL_CLUSTERED_PASS):
         assert st.sphere_tests == segs * len(sph)
     else:   # the two-level list must test fewer spheres than the flat one on a real scene
         assert st.sphere_tests > 0 and (len(sph) < 64 or st.sphere_tests < segs * len(sph))
@@ -382,7 +382,7 @@ def test_one_context_two_streams_is_serialised(gpu_ctx, oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("kernel", [V.KERNEL_PERSISTENT, V.KERNEL_CLUSTERED])
+@pytest.mark.parametrize("kernel", [V.KERNEL_PERSISTENT, V.KERNEL_CLUSTERED, V.KERNEL_CLUSTERED_PASS])
 def test_cost_ordered_dequeue_never_changes_the_frame(gpu_ctx, oracle, kernel):
     """The second and later frames of one shape hand their pixels out in the order of the previous frame's
     per-chunk cost (rtiow_device.h: chunk_order); a changed size, tile or scene starts over.  Scheduling only:

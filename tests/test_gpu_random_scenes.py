@@ -58,7 +58,7 @@ def test_fuzz_regressions(gpu_ctx, oracle, case):
     sph, mat, cam, w, h, base = fuzz_case(case)
     want, segs = oracle.render(sph, mat, cam, V.make_params(w, h, **base))
     gpu_ctx.set_scene(sph, mat)
-    for kernel in (V.KERNEL_PERSISTENT, V.KERNEL_CLUSTERED):
+    for kernel in (V.KERNEL_PERSISTENT, V.KERNEL_CLUSTERED, V.KERNEL_CLUSTERED_PASS):
         got = gpu_ctx.render(cam, V.make_params(w, h, kernel=kernel, **base))
         assert int((got != want).any(axis=2).sum()) == 0 and gpu_ctx.stats().segments == segs, (case, kernel)
 
@@ -80,7 +80,7 @@ def test_random_scene_all_kernels(gpu_ctx, oracle, case):
     base = dict(spp=spp, max_depth=depth, seed=int(rng.integers(0, 2**31)), quantiser=int(rng.integers(0, 2)))
     want, segs = oracle.render(sph, mat, cam, V.make_params(w, h, **base))
     gpu_ctx.set_scene(sph, mat)
-    for kernel in (V.KERNEL_PIXEL, V.KERNEL_PERSISTENT, V.KERNEL_CLUSTERED):
+    for kernel in (V.KERNEL_PIXEL, V.KERNEL_PERSISTENT, V.KERNEL_CLUSTERED, V.KERNEL_CLUSTERED_PASS):
         got = gpu_ctx.render(cam, V.make_params(w, h, kernel=kernel, **base))
         st = gpu_ctx.stats()
         bad = int((got != want).any(axis=2).sum())
@@ -145,7 +145,8 @@ def test_rays_from_outside_the_box_range(gpu_ctx, oracle, n):
     base = dict(spp=6, max_depth=12, seed=5)
     want, segs = oracle.render(sph, mat, cam, V.make_params(w, h, **base))
     gpu_ctx.set_scene(sph, mat)
-    got = gpu_ctx.render(cam, V.make_params(w, h, kernel=V.KERNEL_CLUSTERED, **base))
-    assert gpu_ctx.last_kernel() == V.KERNEL_CLUSTERED
-    st = gpu_ctx.stats()
-    assert int((got != want).any(axis=2).sum()) == 0 and st.segments == segs
+    for kernel in (V.KERNEL_CLUSTERED, V.KERNEL_CLUSTERED_PASS):
+        got = gpu_ctx.render(cam, V.make_params(w, h, kernel=kernel, **base))
+        assert gpu_ctx.last_kernel() == V.KERNEL_CLUSTERED
+        st = gpu_ctx.stats()
+        assert int((got != want).any(axis=2).sum()) == 0 and st.segments == segs

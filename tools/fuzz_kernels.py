@@ -26,6 +26,13 @@ with V.Context(0) as ctx:
         if diff or sf.segments != sc.segments:
             bad += 1
             print(f"MISMATCH case {case}: n={n} {w}x{h} pixels={diff} segs {sf.segments} vs {sc.segments}")
+        # the clustered list with the primary pass forced on (at these sample counts the default leaves it off)
+        pas = ctx.render(cam, V.make_params(w, h, kernel=V.KERNEL_CLUSTERED_PASS, **base))
+        sp = ctx.stats()
+        diff = int((flat != pas).any(axis=2).sum())
+        if diff or sf.segments != sp.segments:
+            bad += 1
+            print(f"MISMATCH (primary pass) case {case}: n={n} {w}x{h} pixels={diff} segs {sf.segments} vs {sp.segments}")
         if case % 3 == 0:   # the same frame as row tiles and as two accumulated dispatches, default kernel choice
             rng = np.random.default_rng(case + 7)
             count, block = int(rng.choice([2, 3, 5])), int(rng.choice([1, 3, 4, 16]))
@@ -35,7 +42,8 @@ with V.Context(0) as ctx:
                 rows = [V.tile_global_row(k, block, r, count) for k in range(nrows)]
                 if len(rows) == 0:
                     continue
-                part = ctx.render(cam, V.make_params(w, h, row_block=block, tile_rank=r, tile_count=count, **base))
+                part = ctx.render(cam, V.make_params(w, h, row_block=block, tile_rank=r, tile_count=count,
+                                                     kernel=V.KERNEL_CLUSTERED_PASS if case % 2 else 0, **base))
                 tiled[rows] = part
             if (tiled != flat).any():
                 bad += 1
@@ -44,13 +52,14 @@ with V.Context(0) as ctx:
                 a_spp = base["spp"] // 2
                 b1 = dict(base); b1["spp"] = a_spp
                 b2 = dict(base); b2["spp"] = base["spp"] - a_spp
-                ctx.render(cam, V.make_params(w, h, accumulate=1, sample_offset=0, **b1))
-                acc = ctx.render(cam, V.make_params(w, h, accumulate=1, sample_offset=a_spp, **b2))
+                kk = V.KERNEL_CLUSTERED_PASS if case % 2 else 0
+                ctx.render(cam, V.make_params(w, h, accumulate=1, sample_offset=0, kernel=kk, **b1))
+                acc = ctx.render(cam, V.make_params(w, h, accumulate=1, sample_offset=a_spp, kernel=kk, **b2))
                 if (acc != flat).any():
                     bad += 1
                     print(f"MISMATCH (accumulate {a_spp}+{base['spp'] - a_spp}) case {case}")
         if (case - first) % 25 == 0:
             print(f"case {case}: n={n} kernel={k} tests/seg flat {sf.sphere_tests / max(1, sf.segments):.0f} "
-                  f"clustered {sc.sphere_tests / max(1, sc.segments):.1f}  ({time.time() - t0:.0f} s)", flush=True)
+                  f"clustered {sc.sphere_tests / max(1, sc.segments):.1f} with the primary pass {sp.sphere_tests / max(1, sp.segments):.1f}  ({time.time() - t0:.0f} s)", flush=True)
 print(f"{cases} cases, {bad} mismatches")
 sys.exit(1 if bad else 0)

@@ -25,7 +25,7 @@ RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_NOMEM, RT_ERR_STATE, RT_ERR
 RT_MODE_CH05, RT_MODE_CH06, RT_MODE_PATH = 5, 6, 13
 RT_QUANT_UNORM8, RT_QUANT_BOOK = 0, 1
 RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_DIELECTRIC = 0, 1, 2
-KERNEL_DEFAULT, KERNEL_PIXEL, KERNEL_PERSISTENT, KERNEL_CLUSTERED = 0, 1, 2, 3
+KERNEL_DEFAULT, KERNEL_PIXEL, KERNEL_PERSISTENT, KERNEL_CLUSTERED, KERNEL_CLUSTERED_PASS = 0, 1, 2, 3, 4
 
 
 class RtUbo5(C.Structure):

@@ -326,7 +326,7 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         // once the camera has come back to an eighth of that range.  Beyond 64
         // diagonals the margins swallow the boxes: flat list.
         uint32_t kernel = prm->kernel;
-        if (kernel == rtiow::KERNEL_CLUSTERED || kernel == rtiow::KERNEL_DEFAULT) {
+        if (kernel == rtiow::KERNEL_CLUSTERED || kernel == rtiow::KERNEL_CLUSTERED_PASS || kernel == rtiow::KERNEL_DEFAULT) {
             double d2 = 0.0;
             for (int k = 0; k < 3; ++k) {
                 const double d = double(cam->origin[k]) - double(ctx->cluster_center[k]);
@@ -517,6 +517,11 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
                     c.tail_iters, c.tail_iters ? c.tail_ticks * 0.01 / c.tail_iters : 0.0, c.tail_sparse_iters,
                     c.tail_sparse_iters ? c.tail_sparse_ticks * 0.01 / c.tail_sparse_iters : 0.0,
                     c.tail_sparse_iters ? double(c.tail_sparse_paths) / c.tail_sparse_iters : 0.0);
+            if (c.pass_stats[0])
+                fprintf(stderr, "primary passes: %llu, %.1f camera rays each, %.2f cluster trips, %.1f paths go on, %.0f shader cycles (trace %.0f, shade %.0f)\n",
+                        c.pass_stats[0], double(c.pass_stats[1]) / c.pass_stats[0], double(c.pass_stats[2]) / c.pass_stats[0],
+                        double(c.pass_stats[3]) / c.pass_stats[0], double(c.pass_stats[4]) / c.pass_stats[0],
+                        double(c.pass_stats[4] - c.pass_stats[5]) / c.pass_stats[0] , double(c.pass_stats[5]) / c.pass_stats[0]);
             if (c.tail_iters)
                 fprintf(stderr, "tail iteration, shader cycles: refill+merge %.0f trace %.0f shade %.0f\n",
                         double(c.tail_cyc[0]) / c.tail_iters, double(c.tail_cyc[1]) / c.tail_iters,

@@ -33,6 +33,7 @@ struct Counters {
     unsigned long long tail_iters, tail_ticks;  // diagnostic builds: iterations / 100 MHz ticks of all waves after running dry
     unsigned long long tail_sparse_iters, tail_sparse_ticks, tail_sparse_paths;  // the sparse ones among them
     unsigned long long tail_cyc[3];  // diagnostic builds: shader cycles of the tail iterations in refill / trace / shade
+    unsigned long long pass_stats[6];  // diagnostic builds, primary pass: passes, camera rays, cluster trips, paths that go on, shader cycles, shade cycles
     // -DRTIOW_DEBUG_TIMELINE builds: waves by the time (50 us bins from the first wave's start) their queue ran dry,
     // they first took the sparse trace, and they finished; iterations after running dry
     unsigned int tl_hist[3][64];
@@ -126,7 +127,9 @@ enum : uint32_t {
     KERNEL_DEFAULT = 0,
     KERNEL_PIXEL = 1,      // one lane per pixel, spp loop inside (v1)
     KERNEL_PERSISTENT = 2, // persistent waves, flat sphere list (every ray tests every sphere)
-    KERNEL_CLUSTERED = 3   // persistent waves, two-level list: cluster boxes, then members per lane
+    KERNEL_CLUSTERED = 3,  // persistent waves, two-level list: cluster boxes, then members per lane
+    KERNEL_CLUSTERED_PASS = 4  // the same with the primary pass (camera rays traced where they are made) whatever the
+                               // samples per pixel; 0 and 3 use it from 16 samples per pixel on.  Reported as 3.
 };
 
 hipError_t launch_ch(const ChArgs& a, hipStream_t stream);

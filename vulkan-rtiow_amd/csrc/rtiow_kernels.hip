@@ -20,6 +20,8 @@
 // against the independent CPU restatement in oracle/.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "rtiow_device.h"
@@ -509,6 +511,14 @@ struct PersistArgs {
     uint32_t pool_pix;     // pixels per pool away from the tail
     uint32_t chunk_pool;   // pixels per pool while whole chunks are handed out (a multiple of kChunkPix)
     uint32_t chunk_until;  // ... which lasts while a queue has at least this many pixels left
+    // the primary pass of the clustered kernels (see "The primary pass" below)
+    uint32_t use_pass;     // != 0: camera rays take the primary pass (enough samples per pixel), 0: straight into the slots
+    uint32_t pass_keep;    // camera paths a wave may keep in LDS beyond its idle slots (records of its own; 0: none)
+    uint32_t pass_cap;     // camera paths a pass may make at most (<= 64: one per lane, and the records must hold them)
+    uint32_t primary_all;  // != 0: no cone cull (degenerate image size, or a lens that leaves the boxes' range)
+    float lens_rho;        // bound of the lens offset |off|, with its margin
+    float h_len, v_len;    // |cam.horizontal|, |cam.vertical|, with their margin
+    float abs_margin;      // absolute slack of the cone test: 2^-16 of the scene's coordinate range
 };
 
 DI void examine_candidate(const float4* lds, uint32_t j, uint32_t n, const Path& p, float& best,
@@ -1326,6 +1336,257 @@ DI void compact_to_slot0(Slot (&sl)[2], uint32_t* scratch) {
     }
 }
 
+// ============================================================================
+// The primary pass (clustered list): camera rays are traced where they are made
+// ============================================================================
+// A third of all segments are camera rays, and the camera rays a wave starts together are consecutive samples of
+// ONE pixel (or of a few neighbours): unlike the scattered rays in the slots they all pass through the same small
+// cone.  So the wave works out ONCE which clusters that cone can reach -- lane b takes box b, one ballot gives a
+// wave-uniform mask -- and every new ray then tests the members of those clusters, and those only, in lock-step
+// with LDS broadcast reads: no box test per ray, no work list, no divergence.  The rays are shaded on the spot;
+// the paths that go on (at depth 1) are handed to idle slots through LDS, so that the general trace -- 32 box tests
+// per ray, work lists, per-lane member walks -- only ever sees scattered rays and always runs on full slots.  A sky
+// pixel never reaches the slots at all.
+//
+// The cone test is only a cull, like the per-ray slab test: it must never drop a cluster that holds a sphere the
+// exact test would accept for some ray of the span.  Rays of a span of pixels i_lo..i_hi of one row (camera_path):
+// origin O + off with |off| <= rho_L (the lens), through the focal-plane point T of its pixel, |T - Tc| <= rho_T
+// for the span's centre Tc.  At parameter l (1 at the focal plane) the ray's point differs from the axis point
+// O + l (Tc - O) by (1 - l) off + l (T - Tc), at most rho_L + l (rho_L + rho_T) = rho_L + kappa s in terms of the
+// distance s along the axis.  A ray point inside a box (centre c, half extent h) therefore has its axis point inside
+// the box inflated by rad = rho_L + kappa s_far, s_far = (max(e.Dn, 0) + |h|_1 + rho_L) / (1 - kappa) bounding s:
+// the AXIS is put through the ordinary slab test against that inflated box.  rho_T, rho_L and rad carry relative
+// margins of 2^-6 .. 2^-8 and an absolute one of 2^-16 of the scene's coordinate range, three orders of magnitude
+// above the binary32 rounding of camera_path and of this test.  The boxes themselves already contain every sphere
+// inflated for the exact test's own rounding (rtiow_clusters.cpp), for origins within their range: launch_path
+// switches the cull off (every cluster, every ray) for a camera whose lens leaves that range.
+constexpr uint32_t kPassSpans = 2;  // spans of consecutive pixels (of one row) a pass hands out at most: one per half of the wave
+constexpr uint32_t kPassRecBytes = 48;  // one waiting camera path: origin, direction, attenuation, RNG, pixel, entry | line
+#ifndef RTIOW_PASS_KEEP
+#define RTIOW_PASS_KEEP 32  // records a wave keeps beyond its idle slots: a pass then runs on min(64, idle + 32) lanes
+#endif
+#ifndef RTIOW_PASS_MIN_IDLE
+#define RTIOW_PASS_MIN_IDLE 1
+#endif
+constexpr uint32_t kPassKeep = RTIOW_PASS_KEEP;
+#ifndef RTIOW_PASS_MIN_SPP
+#define RTIOW_PASS_MIN_SPP 16
+#endif
+constexpr uint32_t kPassMinSpp = RTIOW_PASS_MIN_SPP;  // samples per pixel from which on camera rays take the pass (64 rays: <= 4 pixels)
+constexpr uint32_t kPassMinIdle = RTIOW_PASS_MIN_IDLE;  // idle slots of a wave below which no pass is run for them
+static_assert(kPassKeep <= 32u && (64u - kPassKeep) * kPassRecBytes <= wave_item_bytes(false),
+              "with pass_keep records of its own a wave's other records must fit the work-list area");
+
+struct ConeAxis {  // per lane: the cone of the span this half of the wave looks at
+    float ix, iy, iz, ax, ay, az;  // reciprocal axis direction, -O / direction
+    float dnx, dny, dnz;           // unit axis
+    float kappa, inv1mk;           // slope of the cone radius per unit of axis length; (1 + margin) / (1 - kappa)
+    bool all;                      // degenerate cone: no cull
+};
+
+DI ConeAxis cone_of_span(const PathArgs& a, const PersistArgs& g, uint32_t pix_lo, uint32_t pix_hi) {
+    const RtCamera& c = a.cam;
+    const uint32_t lr = pix_lo / a.width;
+    const uint32_t i_lo = pix_lo - lr * a.width, i_hi = i_lo + (pix_hi - pix_lo);
+    const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
+    const float uc = (0.5f * static_cast<float>(i_lo + i_hi) + 0.5f) * a.inv_wm1;
+    const float vc = (static_cast<float>(j) + 0.5f) * a.inv_hm1;
+    // half the span across, half a pixel up (g.h_len, g.v_len: |horizontal|, |vertical| with their margin)
+    const float rho_t = fma_(0.5f * static_cast<float>(i_hi - i_lo + 1u) * a.inv_wm1, g.h_len, 0.5f * a.inv_hm1 * g.v_len);
+    const float dx = fma_(vc, c.vertical[0], fma_(uc, c.horizontal[0], c.lower_left[0])) - c.origin[0];
+    const float dy = fma_(vc, c.vertical[1], fma_(uc, c.horizontal[1], c.lower_left[1])) - c.origin[1];
+    const float dz = fma_(vc, c.vertical[2], fma_(uc, c.horizontal[2], c.lower_left[2])) - c.origin[2];
+    const float len2 = fma_(dz, dz, fma_(dy, dy, dx * dx));
+    const float inv_len = 1.0f / __builtin_sqrtf(len2);
+    ConeAxis o;
+    o.dnx = dx * inv_len;
+    o.dny = dy * inv_len;
+    o.dnz = dz * inv_len;
+    o.kappa = (g.lens_rho + rho_t) * inv_len;
+    o.all = !(o.kappa < 0.125f);  // (also a NaN or an axis of length 0)
+    o.inv1mk = 1.00390625f / (1.0f - o.kappa);
+    o.ix = slab_rcp(o.dnx);
+    o.iy = slab_rcp(o.dny);
+    o.iz = slab_rcp(o.dnz);
+    o.ax = -c.origin[0] * o.ix;
+    o.ay = -c.origin[1] * o.iy;
+    o.az = -c.origin[2] * o.iz;
+    return o;
+}
+
+DI bool cone_reaches(const PathArgs& a, const PersistArgs& g, const ConeAxis& c, const float4& mid, const float4& half) {
+    const float ex = mid.x - a.cam.origin[0], ey = mid.y - a.cam.origin[1], ez = mid.z - a.cam.origin[2];
+    const float proj = fma_(ez, c.dnz, fma_(ey, c.dny, ex * c.dnx));
+    const float s_far = ((proj > 0.0f ? proj : 0.0f) + ((half.x + half.y) + half.z) + g.lens_rho) * c.inv1mk;
+    const float rad = fma_(c.kappa, s_far, g.lens_rho) * 1.00390625f + g.abs_margin;
+    const float4 fat = make_float4(half.x + rad, half.y + rad, half.z + rad, 0.0f);
+    const float gap = slab_gap(mid, fat, c.ix, c.iy, c.iz, c.ax, c.ay, c.az);
+    return c.all || !(gap < 0.0f);  // (a NaN reaches)
+}
+
+// One 32-bit mask, wave-uniform: bit k set = box first + k (of `boxes`, n of them) can be reached by a ray of one
+// of the spans.  Lanes 0-31 look at one span and lanes 32-63 at the next: two spans per evaluation.
+DI uint32_t cone_mask(const PathArgs& a, const PersistArgs& g, const float4* boxes, uint32_t n, uint32_t first,
+                      const ConeAxis& c0, const uint32_t (&span_lo)[kPassSpans], const uint32_t (&span_hi)[kPassSpans],
+                      uint32_t n_spans) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t b = first + (lane & 31u);
+    const bool in = b < n;
+    const float4 mid = boxes[2u * (in ? b : 0u)], half = boxes[2u * (in ? b : 0u) + 1u];
+    bool reach = in && cone_reaches(a, g, c0, mid, half);
+    const unsigned long long m = __ballot(reach);
+    return static_cast<uint32_t>(m) | static_cast<uint32_t>(m >> 32);
+}
+
+// The same for one SPHERE {centre, r^2} (a slot of the LDS list): can a ray of the span be accepted by the exact test?
+// binary32 evaluates the discriminant with an absolute error below ~22 eps |oc|^2, so an accepted ray passes
+// within sqrt(r^2 + 64 eps |oc|^2) of the centre, and |oc| <= |e| + rho_L for a camera ray; the distance of the centre
+// from the axis comes from the cross product (no cancellation: its error is a few eps |e|, against the absolute margin of
+// 2^-16 of the coordinate range).  In front of the camera the axis counts as a line, behind it as the point O.
+DI bool cone_reaches_sphere(const PathArgs& a, const PersistArgs& g, const ConeAxis& c, const float4& s) {
+    const float ex = s.x - a.cam.origin[0], ey = s.y - a.cam.origin[1], ez = s.z - a.cam.origin[2];
+    const float proj = fma_(ez, c.dnz, fma_(ey, c.dny, ex * c.dnx));
+    const float ee = fma_(ez, ez, fma_(ey, ey, ex * ex));
+    const float cx = ey * c.dnz - ez * c.dny, cy = ez * c.dnx - ex * c.dnz, cz = ex * c.dny - ey * c.dnx;
+    const float d2 = proj > 0.0f ? fma_(cz, cz, fma_(cy, cy, cx * cx)) : ee;
+    const float rr = __builtin_sqrtf(fma_(0x1p-17f, fma_(g.lens_rho, g.lens_rho, ee), s.w)) + g.abs_margin;
+    const float s_far = ((proj > 0.0f ? proj : 0.0f) + rr + g.lens_rho) * c.inv1mk;
+    const float lim = rr + (fma_(c.kappa, s_far, g.lens_rho) * 1.00390625f + g.abs_margin);
+    return s.w >= 0.0f && (c.all || !(d2 > lim * lim));  // (padding slots have r^2 = -inf; a NaN reaches)
+}
+
+// exact test of the sphere in slot `slot` (wave-uniform: LDS broadcast) for the lane's own ray, branch-free
+DI void exact_keyed_lockstep(const float4* slots, const uint32_t* idx_map, uint32_t slot, const Path& p,
+                             unsigned long long& key) {
+    const float4 s = slots[slot];
+    const uint32_t lo = (idx_map[slot] << 16) | slot;
+    const float ocx = p.o.x - s.x, ocy = p.o.y - s.y, ocz = p.o.z - s.z;
+    const float hb = fma_(ocz, p.du.z, fma_(ocy, p.du.y, ocx * p.du.x));
+    const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
+    const float disc = fma_(hb, hb, -cc);
+    const float sq = __builtin_sqrtf(disc);
+    float root = -hb - sq;
+    root = root > kTMin ? root : -hb + sq;
+    // (a discriminant that is negative, -0 or NaN gives no hit, as in examine_keyed)
+    const bool hit = static_cast<int32_t>(__float_as_uint(disc)) >= 0 && root > kTMin;
+    const unsigned long long k2 = hit ? (static_cast<unsigned long long>(__float_as_uint(root)) << 32) | lo : ~0ull;
+    key = k2 < key ? k2 : key;
+}
+
+// Closest hit of the camera rays of one pass (`active` lanes hold one each; the spans are wave-uniform).  Two culls,
+// both wave-uniform: the cluster boxes the spans' cones reach, then -- lane by lane, one sphere each -- the members of
+// those clusters (and the large spheres) the cones reach; what is left, typically the ground and a sphere or two, takes
+// the exact test in lock-step.  Same test, same key, same minimum as trace_clustered for every sphere that can be hit.
+template <bool SUPER>
+DI void primary_trace(const float4* slots, const uint32_t* idx_map, const float4* bounds, const PathArgs& a,
+                      const PersistArgs& g, const Path& p, bool active, const uint32_t (&span_lo)[kPassSpans],
+                      const uint32_t (&span_hi)[kPassSpans], uint32_t n_spans, float& best, int& best_i,
+                      uint32_t& best_o, uint32_t& n_tests, unsigned long long& dbg_trips) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t half = lane & 31u;
+    unsigned long long key = ~0ull;
+    const bool use_all = g.primary_all != 0u;
+    const uint32_t q0 = lane < 32u || n_spans < 2u ? 0u : 1u;
+    const ConeAxis c0 = cone_of_span(a, g, span_lo[q0], span_hi[q0]);
+    // one sphere per lane of each half of the wave (slot_of(half): its slot, ~0u: none) against the cones; the spheres
+    // that are reached, in lock-step against the rays
+    auto spheres = [&](auto&& slot_of) {
+        const uint32_t slot = slot_of(half);
+        const bool in = slot != ~0u;
+        const float4 s = slots[in ? slot : 0u];
+        bool reach = in;
+        if (!use_all) {
+            reach = in && cone_reaches_sphere(a, g, c0, s);
+            n_tests += in ? 1u : 0u;
+        } else {
+            reach = in && s.w >= 0.0f;
+        }
+        const unsigned long long m = __ballot(reach);
+        uint32_t sm = static_cast<uint32_t>(m) | static_cast<uint32_t>(m >> 32);
+        DBG_ADD(dbg_trips, lane == 0u ? __builtin_popcount(sm) : 0);
+        while (sm) {
+            const uint32_t bit = static_cast<uint32_t>(__builtin_ctz(sm));
+            sm &= sm - 1u;
+            exact_keyed_lockstep(slots, idx_map, __builtin_amdgcn_readfirstlane(slot_of(bit)), p, key);
+            if (active) ++n_tests;
+        }
+    };
+    // ---- the large spheres
+    for (uint32_t j = 0; j < a.n_large; j += 32u) spheres([&](uint32_t h) { return j + h < a.n_large ? j + h : ~0u; });
+    // ---- the clusters the cones reach, two at a time
+    uint32_t held = ~0u;  // a reached cluster waiting for a partner
+    auto cluster = [&](uint32_t c) {
+        if (held == ~0u) {
+            held = c;
+            return;
+        }
+        const uint32_t ca = held;
+        held = ~0u;
+        spheres([&](uint32_t h) { return a.n_large_slots + (h < kClusterSize ? ca : c) * kClusterStride + (h & (kClusterSize - 1u)); });
+    };
+    static_assert(kClusterSize == 16u, "two clusters fill one half of the wave");
+    if (!SUPER || a.n_super == 0u) {
+        for (uint32_t g0 = 0; g0 < a.n_clusters; g0 += 32u) {
+            uint32_t cm = 0xFFFFFFFFu;
+            if (!use_all) {
+                cm = cone_mask(a, g, bounds, a.n_clusters, g0, c0, span_lo, span_hi, n_spans);
+                n_tests += g0 + half < a.n_clusters ? 1u : 0u;
+            }
+            if (a.n_clusters - g0 < 32u) cm &= (1u << (a.n_clusters - g0)) - 1u;
+            while (cm) {
+                const uint32_t bit = static_cast<uint32_t>(__builtin_ctz(cm));
+                cm &= cm - 1u;
+                cluster(g0 + bit);
+            }
+        }
+    } else {
+        const float4* sbounds = bounds + 2u * a.n_clusters;
+        for (uint32_t s0 = 0; s0 < a.n_super; s0 += 32u) {
+            uint32_t sm = 0xFFFFFFFFu;
+            if (!use_all) {
+                sm = cone_mask(a, g, sbounds, a.n_super, s0, c0, span_lo, span_hi, n_spans);
+                n_tests += s0 + half < a.n_super ? 1u : 0u;
+            }
+            if (a.n_super - s0 < 32u) sm &= (1u << (a.n_super - s0)) - 1u;
+            // the cluster boxes of four reached super-clusters at a time (4 x kSuperSize = 32 lanes per span)
+            static_assert(kSuperSize == 8u, "four super-clusters fill one 32-bit mask");
+            while (sm) {
+                uint32_t sup[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    sup[u] = sm ? s0 + static_cast<uint32_t>(__builtin_ctz(sm)) : ~0u;
+                    sm &= sm - 1u;  // (0 stays 0)
+                }
+                auto sup_of = [&](uint32_t part) { return part == 0u ? sup[0] : (part == 1u ? sup[1] : (part == 2u ? sup[2] : sup[3])); };
+                const uint32_t my_sup = sup_of(half >> 3);
+                const bool in = my_sup != ~0u;
+                const uint32_t c = (in ? my_sup : 0u) * kSuperSize + (lane & 7u);
+                bool reach = in;
+                if (!use_all) {
+                    const float4 mid = bounds[2u * c], hext = bounds[2u * c + 1u];
+                    reach = in && cone_reaches(a, g, c0, mid, hext);
+                    n_tests += in ? 1u : 0u;
+                }
+                const unsigned long long m = __ballot(reach);
+                uint32_t cm = static_cast<uint32_t>(m) | static_cast<uint32_t>(m >> 32);
+                while (cm) {
+                    const uint32_t bit = static_cast<uint32_t>(__builtin_ctz(cm));
+                    cm &= cm - 1u;
+                    cluster(sup_of(bit >> 3) * kSuperSize + (bit & 7u));
+                }
+            }
+        }
+    }
+    if (held != ~0u) {  // an odd one left
+        const uint32_t ca = held;
+        spheres([&](uint32_t h) { return h < kClusterSize ? a.n_large_slots + ca * kClusterStride + h : ~0u; });
+    }
+    const bool hit = active && key != ~0ull;
+    best = hit ? __uint_as_float(static_cast<uint32_t>(key >> 32)) : __builtin_inff();
+    best_i = hit ? static_cast<int>(key & 0xFFFFu) : -1;
+    best_o = static_cast<uint32_t>(key >> 16) & 0xFFFFu;
+}
+
 #ifndef RTIOW_SMALL_MAX_THREADS
 // largest group of the small-scene clustered variant.  (Tuning: 1024 = one group of sixteen waves, four per SIMD at 128
 // VGPRs: 84 registers spill to scratch and the cover frame takes 10.6 ms instead of 9.8, as in round 1.)
@@ -1370,6 +1631,10 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         reinterpret_cast<unsigned char*>(lds_acc + waves_in_group * (kWaveAccBytes / 8u)) +
         waves_in_group * kWaveLineBytes + wave_in_group * wave_item_bytes(a.n_super != 0u));
     [[maybe_unused]] uint16_t* lds_items = reinterpret_cast<uint16_t*>(lds_results + 128);
+    // (ACCEL) per wave: pass_keep records of camera paths waiting for a slot (three float4 each)
+    [[maybe_unused]] float4* lds_pbuf = reinterpret_cast<float4*>(
+        reinterpret_cast<unsigned char*>(lds_acc + waves_in_group * (kWaveAccBytes / 8u)) +
+        waves_in_group * (kWaveLineBytes + wave_item_bytes(a.n_super != 0u)) + wave_in_group * g.pass_keep * kPassRecBytes);
     if (ACCEL) {
         for (uint32_t i = threadIdx.x; i < g.n_pad; i += blockDim.x) {
             lds_spheres[i] = a.cslots[i];
@@ -1407,6 +1672,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     uint32_t rest_done = 0u;                 // ... and the rest of it
     bool pool_owned = false;                 // the pool is whole chunks of the frame that only this wave renders
     uint32_t cur_line = 0u;                  // line buffer of the chunk being handed out, + 1 (0: its pixels go straight to the frame)
+    [[maybe_unused]] uint32_t pass_n = 0u;   // (clustered) camera paths waiting in the wave's LDS records for an idle slot
     [[maybe_unused]] bool exhausted = false; // the global queue has been drained
 #ifdef RTIOW_DEBUG_TIMELINE
     const unsigned long long tl_start = wall_clock64();
@@ -1417,6 +1683,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     uint32_t n_paths = 0, n_segments = 0, n_tests = 0;
     [[maybe_unused]] uint32_t dbg_slow_trips = 0, dbg_cands = 0, dbg_iters = 0, dbg_sparse = 0;
     [[maybe_unused]] unsigned long long dbg_t_refill = 0, dbg_t_trace = 0, dbg_t_slow = 0, dbg_t_shade = 0;
+    [[maybe_unused]] unsigned long long dbg_pass[6] = {0, 0, 0, 0, 0, 0};
     [[maybe_unused]] const unsigned long long dbg_c0 = DBG_STAMP();
 #ifdef RTIOW_DEBUG_COUNTERS
     const unsigned long long dbg_w0 = wall_clock64();
@@ -1432,8 +1699,8 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         // ---- refill ---------------------------------------------------------
         // Hands out the next `want` samples of the wave's pool, pixel by pixel: on_range(first, n, pixel, entry, sample)
         // is told that the idle slots numbered first .. first+n-1 get samples sample .. sample+n-1 of that pixel (whose
-        // line buffer is cur_line).  Returns how many were handed out (fewer than `want` once the queues are dry or the
-        // accumulator entries are all in use).
+        // line buffer is cur_line); it may refuse them (false), which ends the call.  Returns how many were handed out
+        // (fewer than `want` once the queues are dry or the accumulator entries are all in use).
         auto hand_out = [&](uint32_t want, auto&& on_range) -> uint32_t {
             uint32_t served = 0u;  // wave-uniform
             while (served < want) {  // one trip per pixel touched (1-2 unless spp is tiny)
@@ -1550,67 +1817,276 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     if (lane < kAccWords) lds_acc[(wave_in_group * kAccEntries + cur_entry) * kAccWords + lane] = 0ull;
                 }
                 const uint32_t n = want - served < a.spp - cur_s ? want - served : a.spp - cur_s;
-                on_range(served, n, cur_pix, wave_in_group * kAccEntries + cur_entry, cur_s);
+                if (!on_range(served, n, cur_pix, wave_in_group * kAccEntries + cur_entry, cur_s)) break;  // (the pixel stays open)
                 cur_s += n;
                 served += n;
             }
             return served;
         };
-        bool any_active = false;
-        const unsigned long long idle0 = __ballot(!sl[0].active), idle1 = __ballot(!sl[1].active);
-        const uint32_t n_idle0 = static_cast<uint32_t>(__popcll(idle0));
-        const uint32_t n_idle = n_idle0 + static_cast<uint32_t>(__popcll(idle1));
-        if (ACCEL && SHADE_LDS && n_idle <= 64u) {
-            // The usual case (a third of the 128 slots finish per iteration): the idle slots are numbered across both
-            // slots, lane k generates the camera path of number k -- ONE pass of the camera code on n_idle of 64 lanes
-            // instead of one pass per slot on a third of the lanes each -- and leaves it in the wave's LDS scratch
-            // (the trace's work-list area, idle now), where the lane that owns slot number k picks it up.
-            if (n_idle != 0u) {
-                const uint32_t my_idx[kSlots] = {lane_rank(idle0), n_idle0 + lane_rank(idle1)};
-                bool got[kSlots] = {false, false};
-                uint32_t gen_pix = 0u, gen_s = 0u;
-                const uint32_t granted = hand_out(n_idle, [&](uint32_t first, uint32_t n, uint32_t pix, uint32_t entry, uint32_t s0) {
-                    if (lane - first < n) {  // (unsigned: first <= lane < first + n)
-                        gen_pix = pix;
-                        gen_s = s0 + (lane - first);
+        // ---- shade (used below, and by the primary pass inside the refill) ------
+        // One segment of the path in q has been traced (best_i < 0: it left the scene).  Miss -> sky radiance into the
+        // pixel's accumulator, hit -> scatter; a path that ends bumps its pixel's counter, the lane that completes a pixel
+        // resolves and stores it.  r0, r1: the hit's shading record when the records are not in LDS.
+        auto shade_one = [&](Slot& q, float hit_t, int hit_slot, uint32_t hit_orig, const float4& r0, const float4& r1) {
+            if (__ballot(q.active) == 0ull) return;  // (sparse iterations keep their paths in slot 0)
+            bool finished = false;
+            if (q.active) {
+                ++n_segments;
+                unsigned long long* acc = lds_acc + q.entry * kAccWords;
+                if (hit_slot < 0) {
+                    const f3 rad = sky_radiance(q.p);
+                    atomicAdd(acc + 0, to_fixed(rad.x));  // ds_add_u64: order-independent integer sum
+                    atomicAdd(acc + 1, to_fixed(rad.y));
+                    atomicAdd(acc + 2, to_fixed(rad.z));
+                    finished = true;
+                } else {
+                    const float4 geo = lds_spheres[hit_slot];
+                    ShadeRec m;
+                    if (SHADE_LDS) {
+                        const float4 m0 = lds_shade[2u * hit_orig], m1 = lds_shade[2u * hit_orig + 1u];
+                        m.albedo[0] = m0.x; m.albedo[1] = m0.y; m.albedo[2] = m0.z; m.param = m0.w;
+                        m.inv_r = m1.x; m.kind = __float_as_uint(m1.y);
+                    } else {
+                        m.albedo[0] = r0.x; m.albedo[1] = r0.y; m.albedo[2] = r0.z; m.param = r0.w;
+                        m.inv_r = r1.x; m.kind = __float_as_uint(r1.y);
                     }
-#pragma unroll
-                    for (int r = 0; r < kSlots; ++r)
-                        if (!sl[r].active && my_idx[r] - first < n) {
-                            sl[r].pix = pix;
-                            sl[r].entry = entry;
-                            sl[r].line = cur_line;
-                            got[r] = true;
-                        }
-                });
-                float4* rec = reinterpret_cast<float4*>(lds_results);  // [64] {o, d.x} then [64] {d.y, d.z, rng, -}
-                if (lane < granted) {
-                    Path np;
-                    const uint32_t lr = gen_pix / a.width, i = gen_pix - lr * a.width;
-                    const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
-                    camera_path(a, i, j, a.sample_offset + gen_s, np);
-                    rec[lane] = make_float4(np.o.x, np.o.y, np.o.z, np.du.x);
-                    rec[64u + lane] = make_float4(np.du.y, np.du.z, __uint_as_float(np.rng.state), 0.0f);
+                    if (!scatter(mk(geo.x, geo.y, geo.z), m, hit_t, q.p)) {
+                        finished = true;  // absorbed: radiance 0
+                    } else if (++q.depth >= a.max_depth) {
+                        finished = true;  // depth exhausted: radiance 0
+                    }
                 }
+            }
+            // A finished sample bumps its pixel's counter; the lane that completes the pixel
+            // resolves it.  All adds to the entry were issued by earlier LDS instructions of
+            // this wave (or serialised within this one), so the sums it reads are final.
+            bool completed = false;
+            bool line_full = false;  // this lane's pixel was the last of a line buffer
+            if (finished) {
+                q.active = false;
+                unsigned long long* acc = lds_acc + q.entry * kAccWords;
+                // low half: samples done; high half: the segments they took (<= 65535 each, <= 65536 samples)
+                const uint32_t segs = q.depth < 0xFFFEu ? q.depth + 1u : 0xFFFFu;
+                const unsigned long long before = atomicAdd(acc + 3, 1ull | (static_cast<unsigned long long>(segs) << 32));
+                if (static_cast<uint32_t>(before) + 1u == a.spp) {
+                    completed = true;
+                    const uint32_t colour = close_pixel(a, q.pix, acc[0], acc[1], acc[2]);
+                    const uint32_t line = q.line;
+                    if (line == 0u) {
+                        const uint32_t lr = q.pix / a.width, i = q.pix - lr * a.width;
+                        a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = colour;
+                    } else {  // a pixel of a chunk this wave renders alone: into the line buffer
+                        lds_line[(line - 1u) * kChunkPix + q.pix % kChunkPix] = colour;
+                        uint32_t* meta = lds_line_meta + kLineMetaWords * (line - 1u);
+                        atomicAdd(reinterpret_cast<unsigned long long*>(meta + 2), (before >> 32) + segs);  // the chunk's cost, in LDS
+                        const uint32_t done = atomicAdd(meta, 1u);
+                        line_full = done + 1u == meta[1];
+                    }
+                    // what this pixel cost, for the next frame's chunk order (a global atomic leaves the L2 as a 64-byte
+                    // memory-side request: whole chunks sum theirs in LDS and report once, with the line)
+                    // ... and of the pixels handed out one by one, every fourth speaks for its neighbours
+                    if (a.chunk_cost != nullptr && line == 0u && (q.pix & 3u) == 0u)
+                        atomicAdd(a.chunk_cost + q.pix / kChunkPix, 4ull * ((before >> 32) + segs));
+                }
+            }
+            // Completed pixels (0-2 per iteration): their accumulator entries return to the wave; a pixel that filled
+            // its line buffer has the line stored -- up to 32 consecutive pixels, 128 bytes, the whole line of the
+            // frame in one store.  (A wave's LDS operations are performed in order: the colour written above is there.)
+            unsigned long long done_mask = __ballot(completed);
+            while (done_mask != 0ull) {
+                const int l = __builtin_ctzll(done_mask);
+                done_mask &= done_mask - 1ull;
+                const uint32_t e = __builtin_amdgcn_readlane(q.entry, l);
+                free_entries |= 1ull << (e % kAccEntries);
+                if (__builtin_amdgcn_readlane(static_cast<uint32_t>(line_full), l) != 0u) {
+                    const uint32_t line = __builtin_amdgcn_readlane(q.line, l) - 1u;
+                    const uint32_t first = __builtin_amdgcn_readlane(q.pix, l) / kChunkPix * kChunkPix;
+                    const uint32_t count = g.total_pix - first < kChunkPix ? g.total_pix - first : kChunkPix;
+                    if (lane < count) {
+                        const uint32_t pix = first + lane;
+                        const uint32_t lr = pix / a.width, i = pix - lr * a.width;  // (a chunk may run over the end of a row)
+                        a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = lds_line[line * kChunkPix + lane];
+                    }
+                    if (a.chunk_cost != nullptr && lane == 0u)  // this wave rendered the whole chunk: a plain store
+                        a.chunk_cost[first / kChunkPix] = *reinterpret_cast<const unsigned long long*>(lds_line_meta + kLineMetaWords * line + 2u);
+                    free_lines |= 1u << line;
+                }
+            }
+        };
+        bool any_active = false;
+        if constexpr (ACCEL) {
+            // Idle slots are filled with camera paths that have already taken their first segment: the primary pass
+            // makes up to 64 camera rays at a time (one per lane, consecutive samples of the pool's pixels), traces them
+            // against the clusters their pixels' cones reach, shades them, and leaves the paths that go on in LDS
+            // records, where idle slots pick them up.  A pass makes up to pass_keep paths more than there are idle
+            // slots, so that it runs on (nearly) all 64 lanes; the surplus waits in the wave's records for the next
+            // iteration.  Records pass_keep.. live in the trace's work-list area (idle now) and are always taken first.
+            float4* scratch4 = reinterpret_cast<float4*>(lds_results);
+            auto record = [&](uint32_t k) { return k < g.pass_keep ? lds_pbuf + 3u * k : scratch4 + 3u * (k - g.pass_keep); };
+            for (; g.use_pass != 0u;) {
+                const unsigned long long idle0 = __ballot(!sl[0].active), idle1 = __ballot(!sl[1].active);
+                const uint32_t n_idle0 = static_cast<uint32_t>(__popcll(idle0));
+                const uint32_t n_idle = n_idle0 + static_cast<uint32_t>(__popcll(idle1));
+                if (n_idle == 0u) break;
+                if (pass_n == 0u) {
+                    if (n_idle < kPassMinIdle) break;  // (a pass for a handful of slots costs more than they are worth)
+                    Slot ps;
+                    ps.active = false;
+                    ps.pix = ps.entry = ps.line = ps.depth = 0u;
+                    ps.p.o = ps.p.du = ps.p.att = mk(0.0f, 0.0f, 0.0f);
+                    uint32_t gen_s = 0u;
+                    // the spans of consecutive pixels (of one row) the pass hands out: wave-uniform
+                    uint32_t span_lo[kPassSpans], span_hi[kPassSpans];
+#pragma unroll
+                    for (uint32_t k = 0; k < kPassSpans; ++k) span_lo[k] = span_hi[k] = 0u;
+                    uint32_t n_spans = 0u, last_pix = 0u, row_end = 0u;
+                    const uint32_t want = n_idle + g.pass_keep < g.pass_cap ? n_idle + g.pass_keep : g.pass_cap;
+                    const uint32_t granted = hand_out(want, [&](uint32_t first, uint32_t n, uint32_t pix, uint32_t entry, uint32_t s0) {
+                        // (wave-uniform) the pixel continues the open span, or opens the next one -- a pass stops at the
+                        // third: lanes 0-31 and 32-63 look at one span each when the cones are tested
+                        const bool extends = n_spans != 0u && pix == last_pix + 1u && pix < row_end;
+                        if (!extends && n_spans == kPassSpans) return false;
+                        if (extends) {
+                            if (n_spans == 1u) span_hi[0] = pix; else span_hi[1] = pix;
+                        } else {
+                            if (n_spans == 0u) span_lo[0] = span_hi[0] = pix; else span_lo[1] = span_hi[1] = pix;
+                            ++n_spans;
+                            row_end = (pix / a.width + 1u) * a.width;
+                        }
+                        last_pix = pix;
+                        if (lane - first < n) {  // (unsigned: first <= lane < first + n)
+                            ps.pix = pix;
+                            ps.entry = entry;
+                            ps.line = cur_line;
+                            gen_s = s0 + (lane - first);
+                        }
+                        return true;
+                    });
+                    if (granted == 0u) break;  // queues dry, or all accumulator entries in use (then paths are in flight)
+                    [[maybe_unused]] const unsigned long long tp0 = DBG_STAMP();
+                    DBG_ADD(dbg_pass[0], lane == 0u ? 1u : 0u);
+                    DBG_ADD(dbg_pass[1], lane == 0u ? granted : 0u);
+                    ps.active = lane < granted;
+                    if (ps.active) {
+                        const uint32_t lr = ps.pix / a.width, i = ps.pix - lr * a.width;
+                        const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
+                        camera_path(a, i, j, a.sample_offset + gen_s, ps.p);
+                        ++n_paths;
+                    }
+                    float pb;
+                    int pb_i;
+                    uint32_t pb_o;
+                    primary_trace<!SHADE_LDS>(lds_spheres, lds_cidx, lds_cbounds, a, g, ps.p, ps.active, span_lo, span_hi, n_spans,
+                                              pb, pb_i, pb_o, n_tests, dbg_pass[2]);
+                    float4 pr0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pr1 = pr0;
+                    if (!SHADE_LDS && ps.active && pb_i >= 0) {
+                        const float4* src = reinterpret_cast<const float4*>(a.shade + pb_o);
+                        pr0 = src[0];
+                        pr1 = src[1];
+                    }
+                    [[maybe_unused]] const unsigned long long tp1 = DBG_STAMP();
+                    shade_one(ps, pb, pb_i, pb_o, pr0, pr1);
+                    const unsigned long long going = __ballot(ps.active);
+                    pass_n = static_cast<uint32_t>(__popcll(going));
+                    DBG_ADD(dbg_pass[3], lane == 0u ? pass_n : 0u);
+                    DBG_ADD(dbg_pass[4], lane == 0u ? DBG_STAMP() - tp0 : 0ull);
+                    DBG_ADD(dbg_pass[5], lane == 0u ? DBG_STAMP() - tp1 : 0ull);
+                    if (ps.active) {
+                        float4* rec = record(lane_rank(going));
+                        rec[0] = make_float4(ps.p.o.x, ps.p.o.y, ps.p.o.z, ps.p.du.x);
+                        rec[1] = make_float4(ps.p.du.y, ps.p.du.z, ps.p.att.x, ps.p.att.y);
+                        rec[2] = make_float4(ps.p.att.z, __uint_as_float(ps.p.rng.state), __uint_as_float(ps.pix),
+                                             __uint_as_float(ps.entry | (ps.line << 16)));
+                    }
+                    if (pass_n == 0u) continue;  // every ray left the scene (sky): the slots are as idle as before
+                }
+                // the last `give` records go to the idle slots, numbered across both slots
+                // (a wave's LDS operations are performed in order: the records are there)
+                const uint32_t give = pass_n < n_idle ? pass_n : n_idle;
+                const uint32_t my_idx[kSlots] = {lane_rank(idle0), n_idle0 + lane_rank(idle1)};
 #pragma unroll
                 for (int r = 0; r < kSlots; ++r) {
                     Slot& q = sl[r];
-                    if (got[r]) {  // (a wave's LDS operations are performed in order: the record is there)
-                        const float4 r0 = rec[my_idx[r]], r1 = rec[64u + my_idx[r]];
+                    if (!q.active && my_idx[r] < give) {
+                        const float4* rec = record(pass_n - give + my_idx[r]);
+                        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
                         q.p.o = mk(r0.x, r0.y, r0.z);
                         q.p.du = mk(r0.w, r1.x, r1.y);
-                        q.p.rng = Pcg(__float_as_uint(r1.z));
-                        q.p.att = mk(1.0f, 1.0f, 1.0f);
-                        q.depth = 0u;
+                        q.p.att = mk(r1.z, r1.w, r2.x);
+                        q.p.rng = Pcg(__float_as_uint(r2.y));
+                        q.pix = __float_as_uint(r2.z);
+                        q.entry = __float_as_uint(r2.w) & 0xFFFFu;
+                        q.line = __float_as_uint(r2.w) >> 16;
+                        q.depth = 1u;
                         q.active = true;
-                        ++n_paths;
                     }
+                }
+                pass_n -= give;
+                if (pass_n != 0u) break;  // (more records than idle slots: the slots are full)
+            }
+            if (g.use_pass == 0u) {
+                // Few samples per pixel (launch_path: fewer than kPassMinSpp): the camera rays a wave starts together
+                // belong to dozens of pixels, their common cone is wide and culls little -- they go into the slots
+                // untraced and take the general trace like any other ray.  The idle slots are numbered across both slots,
+                // lane k generates the camera path of number k -- ONE pass of the camera code instead of one per slot
+                // -- and leaves it in the wave's LDS scratch, where the lane that owns slot number k picks it up.
+                const unsigned long long idle0 = __ballot(!sl[0].active), idle1 = __ballot(!sl[1].active);
+                const uint32_t n_idle0 = static_cast<uint32_t>(__popcll(idle0));
+                const uint32_t n_idle = n_idle0 + static_cast<uint32_t>(__popcll(idle1));
+                uint32_t left = n_idle;
+                while (left != 0u) {  // (at most two trips: 64 lanes per trip)
+                    const uint32_t done = n_idle - left;
+                    const uint32_t my_idx[kSlots] = {lane_rank(idle0) - done, n_idle0 + lane_rank(idle1) - done};  // (unsigned: < 64 = this trip)
+                    bool got[kSlots] = {false, false};
+                    uint32_t gen_pix = 0u, gen_s = 0u;
+                    const uint32_t want = left < 64u ? left : 64u;
+                    const uint32_t granted = hand_out(want, [&](uint32_t first, uint32_t n, uint32_t pix, uint32_t entry, uint32_t s0) {
+                        if (lane - first < n) {  // (unsigned: first <= lane < first + n)
+                            gen_pix = pix;
+                            gen_s = s0 + (lane - first);
+                        }
+#pragma unroll
+                        for (int r = 0; r < kSlots; ++r)
+                            if (!sl[r].active && my_idx[r] - first < n) {
+                                sl[r].pix = pix;
+                                sl[r].entry = entry;
+                                sl[r].line = cur_line;
+                                got[r] = true;
+                            }
+                        return true;
+                    });
+                    float4* rec = scratch4;  // [64] {o, d.x} then [64] {d.y, d.z, rng, -}
+                    if (lane < granted) {
+                        Path np;
+                        const uint32_t lr = gen_pix / a.width, i = gen_pix - lr * a.width;
+                        const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
+                        camera_path(a, i, j, a.sample_offset + gen_s, np);
+                        rec[lane] = make_float4(np.o.x, np.o.y, np.o.z, np.du.x);
+                        rec[64u + lane] = make_float4(np.du.y, np.du.z, __uint_as_float(np.rng.state), 0.0f);
+                    }
+#pragma unroll
+                    for (int r = 0; r < kSlots; ++r) {
+                        Slot& q = sl[r];
+                        if (got[r]) {  // (a wave's LDS operations are performed in order: the record is there)
+                            const float4 r0 = rec[my_idx[r]], r1 = rec[64u + my_idx[r]];
+                            q.p.o = mk(r0.x, r0.y, r0.z);
+                            q.p.du = mk(r0.w, r1.x, r1.y);
+                            q.p.rng = Pcg(__float_as_uint(r1.z));
+                            q.p.att = mk(1.0f, 1.0f, 1.0f);
+                            q.depth = 0u;
+                            q.active = true;
+                            ++n_paths;
+                        }
+                    }
+                    if (granted < want) break;
+                    left -= granted;
                 }
             }
             any_active = sl[0].active || sl[1].active;
         } else {
+            const unsigned long long idle0 = __ballot(!sl[0].active), idle1 = __ballot(!sl[1].active);
 #pragma unroll
-            for (int r = 0; r < kSlots; ++r) {  // slot by slot: the flat-list kernel (no scratch), and bursts of > 64 idle slots
+            for (int r = 0; r < kSlots; ++r) {  // slot by slot
                 Slot& q = sl[r];
                 const unsigned long long mask = r == 0 ? idle0 : idle1;
                 const uint32_t rank = lane_rank(mask);
@@ -1624,6 +2100,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                         my_s = s0 + (rank - first);
                         got_sample = true;
                     }
+                    return true;
                 });
                 if (got_sample) {  // start the sample
                     const uint32_t lr = q.pix / a.width, i = q.pix - lr * a.width;
@@ -1698,105 +2175,17 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         // Large scenes keep their shading records in HBM/L2: the records of BOTH slots' hits are asked for here, so that
         // the second slot's round trip (about a microsecond under load) passes while the first slot is shaded.
         [[maybe_unused]] float4 rec0[kSlots], rec1[kSlots];
-        if (!SHADE_LDS) {
-#pragma unroll
-            for (int r = 0; r < kSlots; ++r) {
-                rec0[r] = rec1[r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (sl[r].active && best_i[r] >= 0) {
-                    const float4* src = reinterpret_cast<const float4*>(a.shade + best_o[r]);
-                    rec0[r] = src[0];
-                    rec1[r] = src[1];
-                }
-            }
-        }
 #pragma unroll
         for (int r = 0; r < kSlots; ++r) {
-            Slot& q = sl[r];
-            if (__ballot(q.active) == 0ull) continue;  // (sparse iterations keep their paths in slot 0)
-            bool finished = false;
-            if (q.active) {
-                ++n_segments;
-                unsigned long long* acc = lds_acc + q.entry * kAccWords;
-                if (best_i[r] < 0) {
-                    const f3 rad = sky_radiance(q.p);
-                    atomicAdd(acc + 0, to_fixed(rad.x));  // ds_add_u64: order-independent integer sum
-                    atomicAdd(acc + 1, to_fixed(rad.y));
-                    atomicAdd(acc + 2, to_fixed(rad.z));
-                    finished = true;
-                } else {
-                    const float4 geo = lds_spheres[best_i[r]];
-                    ShadeRec m;
-                    if (SHADE_LDS) {
-                        const float4 m0 = lds_shade[2u * best_o[r]], m1 = lds_shade[2u * best_o[r] + 1u];
-                        m.albedo[0] = m0.x; m.albedo[1] = m0.y; m.albedo[2] = m0.z; m.param = m0.w;
-                        m.inv_r = m1.x; m.kind = __float_as_uint(m1.y);
-                    } else {
-                        m.albedo[0] = rec0[r].x; m.albedo[1] = rec0[r].y; m.albedo[2] = rec0[r].z; m.param = rec0[r].w;
-                        m.inv_r = rec1[r].x; m.kind = __float_as_uint(rec1[r].y);
-                    }
-                    if (!scatter(mk(geo.x, geo.y, geo.z), m, best[r], q.p)) {
-                        finished = true;  // absorbed: radiance 0
-                    } else if (++q.depth >= a.max_depth) {
-                        finished = true;  // depth exhausted: radiance 0
-                    }
-                }
-            }
-            // A finished sample bumps its pixel's counter; the lane that completes the pixel
-            // resolves it.  All adds to the entry were issued by earlier LDS instructions of
-            // this wave (or serialised within this one), so the sums it reads are final.
-            bool completed = false;
-            bool line_full = false;  // this lane's pixel was the last of a line buffer
-            if (finished) {
-                q.active = false;
-                unsigned long long* acc = lds_acc + q.entry * kAccWords;
-                // low half: samples done; high half: the segments they took (<= 65535 each, <= 65536 samples)
-                const uint32_t segs = q.depth < 0xFFFEu ? q.depth + 1u : 0xFFFFu;
-                const unsigned long long before = atomicAdd(acc + 3, 1ull | (static_cast<unsigned long long>(segs) << 32));
-                if (static_cast<uint32_t>(before) + 1u == a.spp) {
-                    completed = true;
-                    const uint32_t colour = close_pixel(a, q.pix, acc[0], acc[1], acc[2]);
-                    const uint32_t line = q.line;
-                    if (line == 0u) {
-                        const uint32_t lr = q.pix / a.width, i = q.pix - lr * a.width;
-                        a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = colour;
-                    } else {  // a pixel of a chunk this wave renders alone: into the line buffer
-                        lds_line[(line - 1u) * kChunkPix + q.pix % kChunkPix] = colour;
-                        uint32_t* meta = lds_line_meta + kLineMetaWords * (line - 1u);
-                        atomicAdd(reinterpret_cast<unsigned long long*>(meta + 2), (before >> 32) + segs);  // the chunk's cost, in LDS
-                        const uint32_t done = atomicAdd(meta, 1u);
-                        line_full = done + 1u == meta[1];
-                    }
-                    // what this pixel cost, for the next frame's chunk order (a global atomic leaves the L2 as a 64-byte
-                    // memory-side request: whole chunks sum theirs in LDS and report once, with the line)
-                    // ... and of the pixels handed out one by one, every fourth speaks for its neighbours
-                    if (a.chunk_cost != nullptr && line == 0u && (q.pix & 3u) == 0u)
-                        atomicAdd(a.chunk_cost + q.pix / kChunkPix, 4ull * ((before >> 32) + segs));
-                }
-            }
-            // Completed pixels (0-2 per iteration): their accumulator entries return to the wave; a pixel that filled
-            // its line buffer has the line stored -- up to 32 consecutive pixels, 128 bytes, the whole line of the
-            // frame in one store.  (A wave's LDS operations are performed in order: the colour written above is there.)
-            unsigned long long done_mask = __ballot(completed);
-            while (done_mask != 0ull) {
-                const int l = __builtin_ctzll(done_mask);
-                done_mask &= done_mask - 1ull;
-                const uint32_t e = __builtin_amdgcn_readlane(q.entry, l);
-                free_entries |= 1ull << (e % kAccEntries);
-                if (__builtin_amdgcn_readlane(static_cast<uint32_t>(line_full), l) != 0u) {
-                    const uint32_t line = __builtin_amdgcn_readlane(q.line, l) - 1u;
-                    const uint32_t first = __builtin_amdgcn_readlane(q.pix, l) / kChunkPix * kChunkPix;
-                    const uint32_t count = g.total_pix - first < kChunkPix ? g.total_pix - first : kChunkPix;
-                    if (lane < count) {
-                        const uint32_t pix = first + lane;
-                        const uint32_t lr = pix / a.width, i = pix - lr * a.width;  // (a chunk may run over the end of a row)
-                        a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = lds_line[line * kChunkPix + lane];
-                    }
-                    if (a.chunk_cost != nullptr && lane == 0u)  // this wave rendered the whole chunk: a plain store
-                        a.chunk_cost[first / kChunkPix] = *reinterpret_cast<const unsigned long long*>(lds_line_meta + kLineMetaWords * line + 2u);
-                    free_lines |= 1u << line;
-                }
+            rec0[r] = rec1[r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (!SHADE_LDS && sl[r].active && best_i[r] >= 0) {
+                const float4* src = reinterpret_cast<const float4*>(a.shade + best_o[r]);
+                rec0[r] = src[0];
+                rec1[r] = src[1];
             }
         }
+#pragma unroll
+        for (int r = 0; r < kSlots; ++r) shade_one(sl[r], best[r], best_i[r], best_o[r], rec0[r], rec1[r]);
         DBG_ADD(dbg_t_refill, t1 - t0);
         DBG_ADD(dbg_t_trace, t2 - t1);
         DBG_ADD(dbg_t_shade, DBG_STAMP() - t2);
@@ -1868,6 +2257,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         atomicAdd(&a.counters->debug[4], dbg_t_trace);
         atomicAdd(&a.counters->debug[5], dbg_t_slow);
         atomicAdd(&a.counters->debug[6], dbg_t_shade);
+        for (int k = 0; k < 6; ++k) atomicAdd(&a.counters->pass_stats[k], dbg_pass[k]);
         {
             const unsigned long long t0w = ~__hip_atomic_load(&a.counters->not_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long b = (wall_clock64() - t0w) / 12500ull;
@@ -2035,7 +2425,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     }
     // default: the clustered list from kClusteredFrom spheres on (cover scene: 2.1x faster than the
     // flat list; frames are byte-identical either way), the flat list for the handful-of-spheres scenes
-    bool accel = kernel == KERNEL_CLUSTERED || (kernel == KERNEL_DEFAULT && a.n >= kClusteredFrom);
+    bool accel = kernel == KERNEL_CLUSTERED || kernel == KERNEL_CLUSTERED_PASS || (kernel == KERNEL_DEFAULT && a.n >= kClusteredFrom);
     constexpr size_t kLdsPerCu = 160u * 1024u - 64u;  // (the kernel's few static __shared__ words come on top of the dynamic part)
     // The clustered list must fit the LDS beside four waves' buffers.  The very largest scenes give up
     // the super-cluster level first (its boxes and second work list), then fall back to the flat list.
@@ -2069,7 +2459,10 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
                            !getenv("RTIOW_DEBUG_NO_SHADE_LDS");  // (tuning only)
     const size_t lds_scene = lds_geo + (shade_lds ? static_cast<size_t>(a.n) * sizeof(ShadeRec) : 0u);
     if (shade_lds && a.n_super != 0u) return hipErrorInvalidValue;  // (cannot happen: see trace_clustered's SUPER)
-    const size_t lds_wave = kWaveAccBytes + kWaveLineBytes + (accel ? item_bytes : 0u);
+    // the clustered kernels' primary pass keeps up to pass_keep camera paths per wave in LDS records of their own; a
+    // large scene with no room for them (C5: one 768-thread group beside 92 KB of list) does without -- its passes then
+    // make no more paths than there are idle slots, and the records sit in the two-level work-list area alone
+    auto wave_bytes = [&](uint32_t keep) { return kWaveAccBytes + kWaveLineBytes + (accel ? item_bytes + keep * kPassRecBytes : 0u); };
     void (*kernel_fn)(PathArgs, PersistArgs) =
         accel ? (shade_lds ? path_persistent_kernel<true, true> : path_persistent_kernel<false, true>)
               : (shade_lds ? path_persistent_kernel<true, false> : path_persistent_kernel<false, false>);
@@ -2086,18 +2479,57 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // (the small-scene variant of the clustered kernel is compiled for groups of at most 512: with the bound at
     // 768 the same source came out 3 % slower on the cover frame)
     const uint32_t t_max = accel ? (shade_lds ? static_cast<uint32_t>(RTIOW_SMALL_MAX_THREADS) : static_cast<uint32_t>(kAccelMaxThreads)) : 1024u;
-    for (uint32_t t = 256u; t <= t_max; t += 256u) {
-        if (pinned != 0u && t != pinned) continue;
-        const size_t need = lds_scene + static_cast<size_t>(t / 64u) * lds_wave;
-        if (need > kLdsPerCu) continue;
-        int blocks = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel_fn, static_cast<int>(t), need);
-        if (e != hipSuccess) return e;
-        if (blocks * static_cast<int>(t) > per_cu * static_cast<int>(threads)) {
-            threads = t;
-            per_cu = blocks;
-            lds = need;
+    uint32_t keep_env = kPassKeep;
+    if (const char* v = getenv("RTIOW_DEBUG_PASS_KEEP")) keep_env = strtoul(v, nullptr, 10) ? kPassKeep : 0u;  // tuning only
+    for (int pass = 0; pass < 2; ++pass) {  // with the records first; without them only if that keeps more waves on a CU
+        const uint32_t keep = accel && pass == 0 ? keep_env : 0u;
+        if (pass == 1 && (!accel || keep_env == 0u)) break;  // (nothing new to try)
+        for (uint32_t t = 256u; t <= t_max; t += 256u) {
+            if (pinned != 0u && t != pinned) continue;
+            const size_t need = lds_scene + static_cast<size_t>(t / 64u) * wave_bytes(keep);
+            if (need > kLdsPerCu) continue;
+            int blocks = 0;
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel_fn, static_cast<int>(t), need);
+            if (e != hipSuccess) return e;
+            if (blocks * static_cast<int>(t) > per_cu * static_cast<int>(threads)) {
+                threads = t;
+                per_cu = blocks;
+                lds = need;
+                g.pass_keep = keep;
+            }
         }
+    }
+    // camera paths a pass may make: one per lane, and no more than the records hold (those beyond pass_keep lie in the
+    // work-list area: 42 of them, or all 64 in the two-level one)
+    g.pass_cap = g.pass_keep + item_bytes / kPassRecBytes;
+    if (g.pass_cap > 64u) g.pass_cap = 64u;
+    if (accel) {
+        // the cone cull of the primary pass (see "The primary pass"): bounds and margins, in double
+        const RtCamera& c = a.cam;
+        auto norm2 = [](const float* v) { return double(v[0]) * v[0] + double(v[1]) * v[1] + double(v[2]) * v[2]; };
+        const double uu = norm2(c.u), vv = norm2(c.v);
+        const double uv = double(c.u[0]) * c.v[0] + double(c.u[1]) * c.v[1] + double(c.u[2]) * c.v[2];
+        // |x u + y v| <= sigma_max |(x, y)|, and the lens sample has |(x, y)| <= lens_radius
+        const double sigma = std::sqrt(0.5 * (uu + vv) + 0.5 * std::sqrt((uu - vv) * (uu - vv) + 4.0 * uv * uv));
+        const double lens = c.lens_radius > 0.0f ? double(c.lens_radius) * sigma * (1.0 + 1.0 / 256.0) : 0.0;
+        g.lens_rho = static_cast<float>(lens);
+        g.h_len = static_cast<float>(std::sqrt(norm2(c.horizontal)) * (1.0 + 1.0 / 64.0));
+        g.v_len = static_cast<float>(std::sqrt(norm2(c.vertical)) * (1.0 + 1.0 / 64.0));
+        double cmax = 0.0, omax = 0.0, dist2 = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            cmax = std::max(cmax, std::fabs(double(a.ccenter[k])));
+            omax = std::max(omax, std::fabs(double(c.origin[k])));
+            dist2 += (double(c.origin[k]) - a.ccenter[k]) * (double(c.origin[k]) - a.ccenter[k]);
+        }
+        const double rmax = std::sqrt(double(a.crmax2));
+        g.abs_margin = static_cast<float>((cmax + omax + 1.5 * rmax) / 65536.0);
+        const bool finite = std::isfinite(lens) && std::isfinite(g.h_len) && std::isfinite(g.v_len) && std::isfinite(g.abs_margin) &&
+                            std::isfinite(dist2);
+        // (the boxes hold for ray origins within rmax of the scene's centre; rtRender re-boxes for a camera beyond 0.95 rmax)
+        const bool in_range = std::sqrt(dist2) + lens <= 0.97 * rmax;
+        g.use_pass = kernel == KERNEL_CLUSTERED_PASS ||
+                     a.spp >= (getenv("RTIOW_DEBUG_PASS_MIN_SPP") ? strtoul(getenv("RTIOW_DEBUG_PASS_MIN_SPP"), nullptr, 10) : kPassMinSpp) ? 1u : 0u;
+        g.primary_all = (finite && in_range && a.width >= 2u && a.height >= 2u && !getenv("RTIOW_DEBUG_NO_CONE")) ? 0u : 1u;
     }
     if (threads == 0u) return hipErrorInvalidValue;  // rtSetScene's sphere limit keeps this from happening
     // persistent grid: fill the chip once; never more slots than samples
