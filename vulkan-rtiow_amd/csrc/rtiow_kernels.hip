@@ -514,6 +514,7 @@ struct PersistArgs {
     // the primary pass of the clustered kernels (see "The primary pass" below)
     uint32_t use_pass;     // != 0: camera rays take the primary pass (enough samples per pixel), 0: straight into the slots
     uint32_t pass_keep;    // camera paths a wave may keep in LDS beyond its idle slots (records of its own; 0: none)
+    uint32_t pass_min_idle;  // idle slots a wave with live paths must have before it runs a pass (kPassMinLanes less the records)
     uint32_t pass_cap;     // camera paths a pass may make at most (<= 64: one per lane, and the records must hold them)
     uint32_t primary_all;  // != 0: no cone cull (degenerate image size, or a lens that leaves the boxes' range)
     float lens_rho;        // bound of the lens offset |off|, with its margin
@@ -1365,15 +1366,15 @@ constexpr uint32_t kPassRecBytes = 48;  // one waiting camera path: origin, dire
 #ifndef RTIOW_PASS_KEEP
 #define RTIOW_PASS_KEEP 32  // records a wave keeps beyond its idle slots: a pass then runs on min(64, idle + 32) lanes
 #endif
-#ifndef RTIOW_PASS_MIN_IDLE
-#define RTIOW_PASS_MIN_IDLE 1
+#ifndef RTIOW_PASS_MIN_LANES
+#define RTIOW_PASS_MIN_LANES 32
 #endif
 constexpr uint32_t kPassKeep = RTIOW_PASS_KEEP;
 #ifndef RTIOW_PASS_MIN_SPP
 #define RTIOW_PASS_MIN_SPP 16
 #endif
 constexpr uint32_t kPassMinSpp = RTIOW_PASS_MIN_SPP;  // samples per pixel from which on camera rays take the pass (64 rays: <= 4 pixels)
-constexpr uint32_t kPassMinIdle = RTIOW_PASS_MIN_IDLE;  // idle slots of a wave below which no pass is run for them
+constexpr uint32_t kPassMinLanes = RTIOW_PASS_MIN_LANES;  // camera rays a pass must be able to make (idle slots + records) to be run
 static_assert(kPassKeep <= 32u && (64u - kPassKeep) * kPassRecBytes <= wave_item_bytes(false),
               "with pass_keep records of its own a wave's other records must fit the work-list area");
 
@@ -1929,7 +1930,11 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 const uint32_t n_idle = n_idle0 + static_cast<uint32_t>(__popcll(idle1));
                 if (n_idle == 0u) break;
                 if (pass_n == 0u) {
-                    if (n_idle < kPassMinIdle) break;  // (a pass for a handful of slots costs more than they are worth)
+                    // (a pass for a handful of camera rays costs as much as one for 64: with fewer records than that the
+                    // idle slots wait until there are enough of them -- unless the wave has nothing else to do)
+                    // (Only in the large-scene variant: small scenes always have room for their 32 records, and the mere
+                    // presence of this test cost the cover frame 3 % -- 8.63 -> 8.88 ms -- through the code around it.)
+                    if (!SHADE_LDS && n_idle < g.pass_min_idle && __ballot(sl[0].active || sl[1].active) != 0ull) break;
                     Slot ps;
                     ps.active = false;
                     ps.pix = ps.entry = ps.line = ps.depth = 0u;
@@ -2501,6 +2506,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     }
     // camera paths a pass may make: one per lane, and no more than the records hold (those beyond pass_keep lie in the
     // work-list area: 42 of them, or all 64 in the two-level one)
+    g.pass_min_idle = kPassMinLanes > g.pass_keep ? kPassMinLanes - g.pass_keep : 1u;
     g.pass_cap = g.pass_keep + item_bytes / kPassRecBytes;
     if (g.pass_cap > 64u) g.pass_cap = 64u;
     if (accel) {
