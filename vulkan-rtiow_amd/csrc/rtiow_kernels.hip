@@ -1924,7 +1924,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             // iteration.  Records pass_keep.. live in the trace's work-list area (idle now) and are always taken first.
             float4* scratch4 = reinterpret_cast<float4*>(lds_results);
             auto record = [&](uint32_t k) { return k < g.pass_keep ? lds_pbuf + 3u * k : scratch4 + 3u * (k - g.pass_keep); };
-            for (; g.use_pass != 0u;) {
+            for (; !SHADE_LDS || g.use_pass != 0u;) {  // (large scenes: always, see below)
                 const unsigned long long idle0 = __ballot(!sl[0].active), idle1 = __ballot(!sl[1].active);
                 const uint32_t n_idle0 = static_cast<uint32_t>(__popcll(idle0));
                 const uint32_t n_idle = n_idle0 + static_cast<uint32_t>(__popcll(idle1));
@@ -2029,10 +2029,12 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 pass_n -= give;
                 if (pass_n != 0u) break;  // (more records than idle slots: the slots are full)
             }
-            if (g.use_pass == 0u) {
+            if (SHADE_LDS && g.use_pass == 0u) {
                 // Few samples per pixel (launch_path: fewer than kPassMinSpp): the camera rays a wave starts together
                 // belong to dozens of pixels, their common cone is wide and culls little -- they go into the slots
-                // untraced and take the general trace like any other ray.  The idle slots are numbered across both slots,
+                // untraced and take the general trace like any other ray.  (Small scenes only: the large-scene variant
+                // has no registers to spare for a second way in, and its general trace is dear enough -- three list
+                // stages -- for the pass to pay even with a wide cone.)  The idle slots are numbered across both slots,
                 // lane k generates the camera path of number k -- ONE pass of the camera code instead of one per slot
                 // -- and leaves it in the wave's LDS scratch, where the lane that owns slot number k picks it up.
                 const unsigned long long idle0 = __ballot(!sl[0].active), idle1 = __ballot(!sl[1].active);
