@@ -345,7 +345,8 @@ def main():
                 "note": "fp32 vector-ALU bound (no dense contraction: MFMA unused by design); flops = "
                         f"tests*{FLOPS_PER_TEST} + segments*{FLOPS_PER_SEGMENT_SHADE}, tests from the kernel's counter "
                         "(flat list: segments*N; clustered list: large spheres + cluster boxes + members of the boxes "
-                        "a ray reaches); kernel time = HIP events on the launch stream over the timed steps",
+                        "a ray reaches, and for camera rays -- traced in the primary pass -- the cone tests of their pixel "
+                        "and the spheres its cone reaches); kernel time = HIP events on the launch stream over the timed steps",
                 "tests_per_segment": st.sphere_tests / max(1, st.segments),
                 "valu_issue": valu_issue,
                 "flat_list_equivalent": {"achieved": flat_equiv, "frac": flat_equiv / FP32_VALU_PEAK_TFLOPS,

@@ -8,7 +8,8 @@
 //   path_persistent_kernel  PATH mode v2, four instantiations <shading records in LDS?, clustered list?>: persistent
 //                           waves, two path slots per lane, per-XCD pixel queues, LDS accumulators, in-kernel resolve.
 //                           <., false> walks the flat sphere list (kernel 2; default below 64 spheres), <., true> the
-//                           two-level clustered list (kernel 3; default from 64 spheres on)
+//                           two-level clustered list (kernel 3; default from 64 spheres on) with camera rays traced in
+//                           the primary pass (primary_trace: kernel 4 forces it at any spp)
 //   order_chunks_kernel     the next frame's chunk sequence from this frame's per-chunk costs (cost-ordered dequeue)
 //   arith_kernel            one operation per element: the arithmetic conformance probe of rtSelfTestArith
 //   (deinterleave_kernel, the multi-GPU frame assembly, lives in rtiow_multi.hip)
@@ -420,6 +421,9 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 //            given consecutive samples of the current pixel, no memory traffic.
 //            Dead lanes are refilled at once, so the sphere loop always runs
 //            with full waves; pools shrink to one pixel as the queue drains.
+//            (ACCEL: the samples go to the primary pass instead -- up to 64 camera rays, one per lane, are made,
+//            traced against the spheres their pixels' cones reach and shaded on the spot; the paths that go on
+//            reach the idle slots through LDS records.  See "The primary pass".)
 //   trace    all lanes walk the LDS sphere list in lock-step (broadcast reads),
 //            branch-free: the sign bit of each discriminant is shifted into a
 //            per-lane candidate word by one v_alignbit.  Only candidates (about
