@@ -121,7 +121,7 @@ typedef struct RtParams {
                             list from 64 on); 1 one lane per pixel; 2 persistent, flat list; 3 persistent,
                             clustered list; 4 = 3 with the primary pass (camera rays traced where they are
                             made, against the spheres their pixels' cones reach) at any spp -- 0 and 3 use
-                            it from 16 samples per pixel on (scenes too large for their shading records to
+                            it from 8 samples per pixel on (scenes too large for their shading records to
                             sit in LDS: always); rtGetLastKernel reports 3.  Frames are
                             identical by contract. */
     /* Progressive accumulation, the frame loop of RTCHAP06/main.cpp:304-360 with a running

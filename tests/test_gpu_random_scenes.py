@@ -150,3 +150,47 @@ def test_rays_from_outside_the_box_range(gpu_ctx, oracle, n):
         assert gpu_ctx.last_kernel() == V.KERNEL_CLUSTERED
         st = gpu_ctx.stats()
         assert int((got != want).any(axis=2).sum()) == 0 and st.segments == segs
+
+
+@pytest.mark.parametrize("case", range(14))
+def test_primary_pass_extreme_cameras(gpu_ctx, oracle, case):
+    """The cone cull of the primary pass (RtParams.kernel 4 forces it at these sample counts) at the edges of its
+    derivation: lenses wider than the focus distance (the cone degenerates: no cull), a field of view of 179 degrees,
+    images of two rows / two columns / four pixels (footprints as wide as the view), a camera inside a glass ball,
+    inside the sphere field and skimming the ground, a tilted camera, sample counts around the 64 lanes of a pass."""
+    sph, mat = V.make_cover_scene(3, 6)
+    cams = [
+        # (from, at, vfov, aperture, focus, w, h, spp)
+        ((13, 2, 3), (0, 0, 0), 20.0, 6.0, 1.0, 40, 24, 9),        # lens radius 3 at focus distance 1
+        ((13, 2, 3), (0, 0, 0), 20.0, 2.0, 10.0, 40, 24, 9),       # a very wide lens
+        ((3, 0.6, 2), (0, 0.5, 0), 179.0, 0.0, 1.0, 33, 17, 5),    # fish-eye
+        ((13, 2, 3), (0, 0, 0), 20.0, 0.1, 10.0, 64, 2, 70),       # two rows (the oracle, like the UBO of main.cpp:103-120, wants at least two)
+        ((13, 2, 3), (0, 0, 0), 20.0, 0.1, 10.0, 2, 48, 70),       # two columns
+        ((13, 2, 3), (0, 0, 0), 20.0, 0.1, 10.0, 2, 2, 300),       # four pixels
+        ((0.0, 1.0, 0.0), (4, 1, 0), 60.0, 0.0, 1.0, 48, 32, 6),   # inside the big glass ball at the origin
+        ((0.3, 0.25, 0.4), (4, 0.2, 3), 90.0, 0.05, 2.0, 48, 32, 6),  # between the small spheres
+        ((5, 0.01, 5), (0, 0.2, 0), 50.0, 0.02, 5.0, 64, 20, 8),   # skimming the ground
+        ((13, 2, 3), (0, 0, 0), 20.0, 0.1, 10.0, 31, 19, 64),      # exactly one pass per pixel
+        ((13, 2, 3), (0, 0, 0), 20.0, 0.1, 10.0, 31, 19, 65),
+        ((13, 2, 3), (0, 0, 0), 20.0, 0.1, 10.0, 31, 19, 63),
+        ((-7, 9, -4), (1, 0, 2), 35.0, 0.3, 11.0, 50, 30, 7),      # from above, tilted (up vector below)
+        ((40, 6, 9), (0, 0, 0), 8.0, 0.0, 40.0, 60, 40, 5),        # far and narrow
+    ]
+    frm, at, fov, ap, focus, w, h, spp = cams[case]
+    up = (0.3, 1, 0.2) if case == 12 else (0, 1, 0)
+    cam = V.make_camera(frm, at, up, fov, w / h, ap, focus)
+    base = dict(spp=spp, max_depth=12, seed=90 + case)
+    want, segs = oracle.render(sph, mat, cam, V.make_params(w, h, **base))
+    gpu_ctx.set_scene(sph, mat)
+    for kernel in (V.KERNEL_CLUSTERED_PASS, V.KERNEL_DEFAULT):
+        got = gpu_ctx.render(cam, V.make_params(w, h, kernel=kernel, **base))
+        assert gpu_ctx.last_kernel() == V.KERNEL_CLUSTERED
+        assert int((got != want).any(axis=2).sum()) == 0 and gpu_ctx.stats().segments == segs, (case, kernel)
+    # ... and as row tiles (the cone of a span uses the tile's global rows)
+    tiled = np.zeros_like(want)
+    for r in range(3):
+        rows = [V.tile_global_row(k, 2, r, 3) for k in range(V.tile_row_count(h, 2, r, 3))]
+        if rows:
+            tiled[rows] = gpu_ctx.render(cam, V.make_params(w, h, kernel=V.KERNEL_CLUSTERED_PASS, row_block=2, tile_rank=r,
+                                                            tile_count=3, **base))
+    assert np.array_equal(tiled, want), case

@@ -129,7 +129,7 @@ enum : uint32_t {
     KERNEL_PERSISTENT = 2, // persistent waves, flat sphere list (every ray tests every sphere)
     KERNEL_CLUSTERED = 3,  // persistent waves, two-level list: cluster boxes, then members per lane
     KERNEL_CLUSTERED_PASS = 4  // the same with the primary pass (camera rays traced where they are made) whatever the
-                               // samples per pixel; 0 and 3 use it from 16 samples per pixel on (large scenes: always).
+                               // samples per pixel; 0 and 3 use it from 8 samples per pixel on (large scenes: always).
                                // Reported as 3.
 };
 
