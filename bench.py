@@ -346,7 +346,10 @@ def main():
                         f"tests*{FLOPS_PER_TEST} + segments*{FLOPS_PER_SEGMENT_SHADE}, tests from the kernel's counter "
                         "(flat list: segments*N; clustered list: large spheres + cluster boxes + members of the boxes "
                         "a ray reaches, and for camera rays -- traced in the primary pass -- the cone tests of their pixel "
-                        "and the spheres its cone reaches); kernel time = HIP events on the launch stream over the timed steps",
+                        "and the spheres its cone reaches); kernel time = HIP events on the launch stream over the timed steps; "
+                        "the fraction rates EXECUTED tests: the primary pass of round 2 removed a third of them (58.3 -> 39.0 per "
+                        "segment on the cover frame) while the frame got 9-14 % faster, so it fell from 0.176 to 0.133 -- "
+                        "valu_issue (instruction issue against the measured v_fma_f32 rate) is the utilisation figure",
                 "tests_per_segment": st.sphere_tests / max(1, st.segments),
                 "valu_issue": valu_issue,
                 "flat_list_equivalent": {"achieved": flat_equiv, "frac": flat_equiv / FP32_VALU_PEAK_TFLOPS,

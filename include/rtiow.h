@@ -140,7 +140,9 @@ typedef struct RtStats {
     uint64_t sphere_tests;   /* ray-sphere and ray-box tests executed, from the kernel's own counter:
                                 segments * n_spheres for the flat list and the one-lane-per-pixel kernel,
                                 far fewer for the clustered list (large spheres + cluster boxes +
-                                members of the boxes a ray reaches)                         */
+                                members of the boxes a ray reaches; camera rays traced in the
+                                primary pass: the cone tests of their pixels + the spheres the
+                                cones reach)                                                */
     uint64_t bytes_written;  /* algorithmic framebuffer bytes of the last render          */
     uint32_t rows_rendered;
     uint32_t n_spheres;
