@@ -236,7 +236,8 @@ def test_clustered_kernel_keeps_three_waves_per_simd():
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
         if m and name and "path_persistent_kernel" in name:
             assert int(m.group(1)) == 0, (name, "spills to scratch")
-    clustered = {k: v for k, v in seen.items() if "path_persistent_kernelILb" in k and k.endswith("ELb1EEEvNS_8PathArgsENS0_11PersistArgsE")}
+    # (the small-scene variant <true, true> comes from the second compilation of rtiow_kernels.hip: `make asm` runs both)
+    clustered = {k: v for k, v in seen.items() if re.search(r"path_persistent_kernelILb[01]ELb1EEEv", k)}
     assert len(clustered) == 2, seen.keys()
     for k, v in clustered.items():
         assert v <= 168, (k, v)

@@ -111,6 +111,7 @@ DI f3 gnormalize(f3 a) {
     return mk(a.x / l, a.y / l, a.z / l);
 }
 
+#ifndef RTIOW_TU_SMALL_CLUSTERED
 // 16x16 workgroup as raytrace06.comp:2; ceil-div grid with a bounds check
 // (fixes the fixed 64x64 / floor-div dispatches of main.cpp:321 and
 // RTCHAP05 main.cpp:306).  One packed 32-bit store per lane: a wave writes
@@ -179,6 +180,8 @@ __global__ __launch_bounds__(256) void ch_kernel(ChArgs a) {
     a.dst[static_cast<size_t>(gy) * a.dst_stride + gx] =
         pack_rgb(quant_unorm8(col.x), quant_unorm8(col.y), quant_unorm8(col.z));
 }
+
+#endif  // RTIOW_TU_SMALL_CLUSTERED
 
 // ============================================================================
 // PATH mode building blocks (BUILD-SPEC: SURVEY.md section 9)
@@ -355,6 +358,7 @@ DI int closest_hit_simple(const float4* lds, uint32_t n, const Path& p, float& b
     return best_i;
 }
 
+#ifndef RTIOW_TU_SMALL_CLUSTERED
 // ============================================================================
 // PATH v1: one lane per pixel (reference form; kept as a cross-check and ablation)
 // ============================================================================
@@ -404,6 +408,8 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
         atomicAdd(&a.counters->segments, static_cast<unsigned long long>(blk_segments));
     }
 }
+
+#endif  // RTIOW_TU_SMALL_CLUSTERED
 
 // ============================================================================
 // PATH v2: persistent waves, per-pixel LDS accumulators, ballot refill, candidate bitmasks
@@ -508,6 +514,7 @@ struct Slot {
     bool active;
 };
 
+}  // namespace (PersistArgs is shared with the second compilation of this file: see the end of it)
 struct PersistArgs {
     uint32_t n_pad;        // sphere list padded to a multiple of kBlockSph
     uint32_t total_pix;    // pixels of this tile (the global queue counts pixels)
@@ -525,6 +532,9 @@ struct PersistArgs {
     float h_len, v_len;    // |cam.horizontal|, |cam.vertical|, with their margin
     float abs_margin;      // absolute slack of the cone test: 2^-16 of the scene's coordinate range
 };
+using PersistentKernelFn = void (*)(PathArgs, PersistArgs);
+PersistentKernelFn small_clustered_kernel();  // path_persistent_kernel<true, true>, from the second compilation of this file
+namespace {
 
 DI void examine_candidate(const float4* lds, uint32_t j, uint32_t n, const Path& p, float& best,
                           int& best_i) {
@@ -2291,6 +2301,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
 #endif
 }
 
+#ifndef RTIOW_TU_SMALL_CLUSTERED
 // ============================================================================
 // arithmetic conformance probe (tests/test_gpu_parity.py::test_arith_bit_exact)
 // ============================================================================
@@ -2403,7 +2414,17 @@ __global__ __launch_bounds__(1024) void order_chunks_kernel(unsigned long long* 
     }
 }
 
+#endif  // RTIOW_TU_SMALL_CLUSTERED
 }  // namespace
+
+// The small-scene clustered kernel -- the default kernel of the headline frame -- is compiled in a second pass over this
+// file (Makefile: -DRTIOW_TU_SMALL_CLUSTERED, object rtiow_kernels_small.o) with the compiler's other instruction
+// scheduler, -mllvm -amdgpu-sched-strategy=iterative-ilp: same source, same registers (159, no spills), cover frame
+// 8.64 -> 8.40 ms, one eighth of it 1.46 -> 1.41 (interleaved A/B, tools/ab_bench.py).  The large-scene variant spills
+// under that scheduler (C5 1.16 -> 1.22 s) and the flat-list kernels lose 1 % to it, so they stay with the default.
+#ifdef RTIOW_TU_SMALL_CLUSTERED
+PersistentKernelFn small_clustered_kernel() { return path_persistent_kernel<true, true>; }
+#else
 
 hipError_t launch_order_chunks(unsigned long long* cost, uint32_t* order, uint32_t n_chunks, uint32_t spp, hipStream_t stream) {
     hipLaunchKernelGGL(order_chunks_kernel, dim3(1), dim3(kOrderBins), 0, stream, cost, order, n_chunks,
@@ -2476,7 +2497,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // make no more paths than there are idle slots, and the records sit in the two-level work-list area alone
     auto wave_bytes = [&](uint32_t keep) { return kWaveAccBytes + kWaveLineBytes + (accel ? item_bytes + keep * kPassRecBytes : 0u); };
     void (*kernel_fn)(PathArgs, PersistArgs) =
-        accel ? (shade_lds ? path_persistent_kernel<true, true> : path_persistent_kernel<false, true>)
+        accel ? (shade_lds ? small_clustered_kernel() : path_persistent_kernel<false, true>)
               : (shade_lds ? path_persistent_kernel<true, false> : path_persistent_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsPerCu));
@@ -2578,5 +2599,7 @@ hipError_t launch_arith(uint32_t op, const float* a, const float* b, const float
                        out, n);
     return hipGetLastError();
 }
+
+#endif  // RTIOW_TU_SMALL_CLUSTERED
 
 }  // namespace rtiow
