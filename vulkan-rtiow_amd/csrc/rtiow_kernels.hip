@@ -487,6 +487,13 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 #define RTIOW_POOL_WORK 40000u
 #endif
 constexpr uint32_t kPoolWork = RTIOW_POOL_WORK;
+#ifndef RTIOW_LONG_FROM
+#define RTIOW_LONG_FROM 12
+#endif
+#ifndef RTIOW_LONG_WEIGHT
+#define RTIOW_LONG_WEIGHT 128
+#endif
+constexpr uint32_t kLongFrom = RTIOW_LONG_FROM, kLongWeight = RTIOW_LONG_WEIGHT;  // cost of a path of more segments than kLongFrom, for the chunk order
 constexpr int kSlots = 2;           // path slots per lane
 constexpr uint32_t kBlockSph = 32;  // spheres per candidate word
 #ifndef RTIOW_SPARSE_MAX
@@ -1882,7 +1889,11 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 q.active = false;
                 unsigned long long* acc = lds_acc + q.entry * kAccWords;
                 // low half: samples done; high half: the segments they took (<= 65535 each, <= 65536 samples)
-                const uint32_t segs = q.depth < 0xFFFEu ? q.depth + 1u : 0xFFFFu;
+                // (A long path counts kLongWeight-fold: what ends a frame is not the work of its last chunks but the LENGTH of
+                // the paths born in them -- fifty bounces at one iteration each -- so chunks in which long paths occur are to go
+                // out first whatever their average; the sum only orders the chunks of the next frame.)
+                const uint32_t segs1 = q.depth < 0xFFFEu ? q.depth + 1u : 0xFFFFu;
+                const uint32_t segs = segs1 > kLongFrom ? (segs1 * kLongWeight < 0xFFFFu ? segs1 * kLongWeight : 0xFFFFu) : segs1;
                 const unsigned long long before = atomicAdd(acc + 3, 1ull | (static_cast<unsigned long long>(segs) << 32));
                 if (static_cast<uint32_t>(before) + 1u == a.spp) {
                     completed = true;
@@ -1900,9 +1911,15 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     }
                     // what this pixel cost, for the next frame's chunk order (a global atomic leaves the L2 as a 64-byte
                     // memory-side request: whole chunks sum theirs in LDS and report once, with the line)
-                    // ... and of the pixels handed out one by one, every fourth speaks for its neighbours
-                    if (a.chunk_cost != nullptr && line == 0u && (q.pix & 3u) == 0u)
-                        atomicAdd(a.chunk_cost + q.pix / kChunkPix, 4ull * ((before >> 32) + segs));
+                    // ... and of the pixels handed out one by one, every fourth speaks for its neighbours -- unless a long
+                    // path ended in this one: those are what the order is for, and too rare to be sampled
+                    if (a.chunk_cost != nullptr && line == 0u) {
+                        const unsigned long long cost = (before >> 32) + segs;
+                        if (cost >= static_cast<unsigned long long>(a.spp) * kLongFrom + kLongFrom * kLongWeight)  // (one long path at least)
+                            atomicAdd(a.chunk_cost + q.pix / kChunkPix, cost);
+                        else if ((q.pix & 3u) == 0u)
+                            atomicAdd(a.chunk_cost + q.pix / kChunkPix, 4ull * cost);
+                    }
                 }
             }
             // Completed pixels (0-2 per iteration): their accumulator entries return to the wave; a pixel that filled
