@@ -2591,6 +2591,15 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     if (const char* v = getenv("RTIOW_DEBUG_GRID")) grid = strtoul(v, nullptr, 10);  // tuning only
     if (grid < 1) grid = 1;
     g.total_waves = static_cast<uint32_t>(grid) * (threads / 64u);
+    // A pool is never more than a share of what a wave gets in all: pools are of one size to the end of a queue (no look
+    // at the head), and a cheap scene asks for large ones -- the three-sphere frame of BASELINE config 2, 29 pixels per
+    // wave, was dealt in pools of 40 and took 1.93 ms instead of 0.8 (RTIOW_DEBUG_POOL_SHARE: tuning only).
+    {
+        uint32_t share = 4u;
+        if (const char* v = getenv("RTIOW_DEBUG_POOL_SHARE")) share = strtoul(v, nullptr, 10);
+        const uint32_t cap = share ? g.total_pix / (g.total_waves * share) : ~0u;
+        if (g.pool_pix > (cap < 1u ? 1u : cap)) g.pool_pix = cap < 1u ? 1u : cap;
+    }
     // Whole-chunk pools (one store per 128-byte line of the frame) until a queue is down to about 24 pixels per wave that
     // draws from it: when the switch to small pools comes, every wave still holds half a chunk on average, and the small
     // pools have to fill the time until the last of them is through (RTIOW_DEBUG_CHUNK_UNTIL: tuning only).
