@@ -2499,6 +2499,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     pool_samples = pool_samples < 256u ? 256u : (pool_samples > 4096u ? 4096u : pool_samples);
     g.pool_pix = pool_samples / a.spp;  // a few pixels per pool; one pixel when spp is large
     g.pool_pix = g.pool_pix < 1u ? 1u : (g.pool_pix > 256u ? 256u : g.pool_pix);
+    if (const char* v = getenv("RTIOW_DEBUG_POOL_PIX")) g.pool_pix = strtoul(v, nullptr, 10);  // tuning only
     // LDS per workgroup: the sphere list (16 B per slot; clustered: + 4 B per slot of indices and
     // 32 B per cluster box); while the scene is small, the shading records too (32 B each);
     // 2 KiB of pixel accumulator entries and 0.5 KiB of line buffers per wave (clustered: + 2-3 KiB of work lists
