@@ -458,7 +458,7 @@ def test_error_behaviour(gpu_ctx, oracle):
     sph, mat = V.make_three_sphere_scene()
     fresh.set_scene(sph, mat)
     for bad in (V.make_params(8, 8, spp=0), V.make_params(1, 8), V.make_params(8, 8, mode=99),
-                V.make_params(8, 8, quantiser=7), V.make_params(8, 8, tile_rank=2, tile_count=2)):
+                V.make_params(8, 8, quantiser=7), V.make_params(8, 8, tile_rank=2, tile_count=2), V.make_params(8, 8, kernel=5)):
         with pytest.raises(V.RtError) as e:
             fresh.render(cam, bad)
         assert e.value.code == V.RT_ERR_INVALID

@@ -441,6 +441,7 @@ int rtRender(RtContext* ctx, const RtCamera* cam, const RtParams* params, void* 
     if (params->accumulate && (params->sample_offset > 65536u - params->spp))
         return fail(ctx, RT_ERR_INVALID, "rtRender: sample_offset + spp must not exceed 65536");
     if (params->quantiser > RT_QUANT_BOOK) return fail(ctx, RT_ERR_INVALID, "rtRender: unknown quantiser");
+    if (params->kernel > rtiow::KERNEL_CLUSTERED_PASS) return fail(ctx, RT_ERR_INVALID, "rtRender: unknown kernel variant (0..4)");
     return render_common(ctx, false, nullptr, cam, params, dst, dst_pitch, dst_is_device, stream);
 }
 
