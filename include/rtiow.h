@@ -231,6 +231,17 @@ const char* rtMultiGetLastError(const RtMulti* m); /* m may be NULL: errors of r
 int rtMultiSelfTestHost(const uint32_t* full, uint32_t width, uint32_t height, uint32_t row_block,
                         uint32_t n_tiles, uint32_t* out);
 
+/* CPU check of the primary pass's cull (the kernels' own functions compiled for the host): for the span of pixels
+ * pix_lo..pix_hi (indices row * width + column, one row) of a width x height image, which of the n_spheres spheres and
+ * of the n_boxes boxes (six floats each: centre, half extent) can a camera ray of the span reach?  range_center /
+ * range_rmax: the ray origins the scene's boxes are valid for (rtSetScene: two scene diagonals around its centre).
+ * sphere_reach / box_reach receive one byte each (1 = may be reached).  Returns 1, 0 when the cull is off for this
+ * camera (everything reached), or a negative RT_ERR_* code.  The test: no ray of the span, sampled as the camera
+ * code samples it, hits a sphere or enters a box marked 0. */
+int rtConeSelfTestHost(const RtCamera* cam, uint32_t width, uint32_t height, uint32_t pix_lo, uint32_t pix_hi,
+                       const float* range_center, float range_rmax, const RtSphere* spheres, uint32_t n_spheres,
+                       const float* boxes, uint32_t n_boxes, uint8_t* sphere_reach, uint8_t* box_reach);
+
 /* ---- host-side helpers (no GPU needed) ---------------------------------- */
 
 /* RTCHAP06/main.cpp:101-120: width/height -> the UBO the reference fills

@@ -241,3 +241,71 @@ def test_clustered_kernel_keeps_three_waves_per_simd():
     assert len(clustered) == 2, seen.keys()
     for k, v in clustered.items():
         assert v <= 168, (k, v)
+
+
+def _camera_rays(V, cam, width, height, pix_lo, pix_hi, n, rng):
+    """n camera rays of the span pix_lo..pix_hi as camera_path samples them (float64; rtiow_kernels.hip)."""
+    c = {k: np.array(getattr(cam, k), np.float64) for k in ("origin", "lower_left", "horizontal", "vertical", "u", "v")}
+    pix = rng.integers(pix_lo, pix_hi + 1, n)
+    i, j = pix % width, pix // width
+    # the corners and edges of the pixel as well as its inside, the rim of the lens as well as its disk
+    xi = np.where(rng.random(n) < 0.3, rng.integers(0, 2, n).astype(float), rng.random(n))
+    eta = np.where(rng.random(n) < 0.3, rng.integers(0, 2, n).astype(float), rng.random(n))
+    u = (i + xi) / (width - 1)
+    v = (j + eta) / (height - 1)
+    r = np.where(rng.random(n) < 0.3, 1.0, np.sqrt(rng.random(n))) * float(cam.lens_radius)
+    phi = rng.random(n) * 2 * np.pi
+    off = (r * np.cos(phi))[:, None] * c["u"] + (r * np.sin(phi))[:, None] * c["v"]
+    o = c["origin"] + off
+    d = c["lower_left"] + u[:, None] * c["horizontal"] + v[:, None] * c["vertical"] - c["origin"] - off
+    return o, d / np.linalg.norm(d, axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_primary_pass_cone_cull_is_conservative(case):
+    """The cull of the primary pass (rtiow_kernels.hip, "The primary pass") run on the host through rtConeSelfTestHost --
+    the kernels' own cone_of_span / cone_reaches / cone_reaches_sphere -- against brute force: thousands of camera rays
+    of a span, sampled in float64 as camera_path samples them (pixel corners and the rim of the lens included), must not
+    hit a sphere or enter a box the cull has marked unreachable.  The cull must also cull: most of the scene is out."""
+    import vulkan_rtiow_amd as V
+    rng = np.random.default_rng(4200 + case)
+    width, height = int(rng.integers(2, 400)), int(rng.integers(2, 300))
+    scale = float(rng.choice([0.05, 1.0, 1.0, 40.0]))
+    frm = rng.normal(size=3) * rng.choice([0.5, 3.0, 12.0]) * scale
+    at = rng.normal(size=3) * 0.5 * scale
+    aperture = float(rng.choice([0.0, 0.0, 0.1, 0.6])) * scale
+    focus = float(np.linalg.norm(frm - at)) * float(rng.uniform(0.3, 1.5)) + 1e-3
+    cam = V.make_camera(tuple(frm), tuple(at), (0, 1, 0), float(rng.uniform(5, 150)), width / height, aperture, focus)
+    n = 300
+    sph = np.zeros(n, V.SPHERE_DTYPE)
+    sph["cx"], sph["cy"], sph["cz"] = (rng.uniform(-8, 8, (3, n)) * scale)
+    sph["radius"] = rng.uniform(0.05, 0.6, n) * scale * rng.choice([1.0, 1.0, -1.0, 4.0], n)
+    mid = rng.uniform(-8, 8, (200, 3)) * scale
+    half = rng.uniform(0.05, 1.5, (200, 3)) * scale
+    boxes = np.concatenate([mid, half], axis=1).astype(np.float32)
+    row = int(rng.integers(0, height))
+    lo = row * width + int(rng.integers(0, width))
+    hi = min(lo + int(rng.choice([0, 0, 1, 7, 40])), (row + 1) * width - 1)
+    centre = np.zeros(3, np.float32)
+    rmax = 2.0 * float(np.linalg.norm([16, 16, 16])) * scale + 2.0 * float(np.linalg.norm(frm))   # the camera is in range
+    cull, sreach, breach = V.cone_selftest_host(cam, width, height, lo, hi, centre, rmax, sph, boxes)
+    o, d = _camera_rays(V, cam, width, height, lo, hi, 6000, rng)
+    c = np.stack([sph["cx"], sph["cy"], sph["cz"]], axis=1).astype(np.float64)
+    r2 = sph["radius"].astype(np.float64) ** 2
+    oc = o[:, None, :] - c[None, :, :]
+    hb = np.einsum("nsk,nk->ns", oc, d)
+    disc = hb * hb - (np.einsum("nsk,nsk->ns", oc, oc) - r2[None, :])
+    far_root = -hb + np.sqrt(np.maximum(disc, 0.0))
+    hit = ((disc >= 0.0) & (far_root > 0.0)).any(axis=0)          # some ray of the span meets the sphere ahead of its origin
+    assert not (hit & ~sreach).any(), (case, np.nonzero(hit & ~sreach)[0][:5])
+    b32 = boxes.astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / d
+        t1 = (b32[None, :, :3] - b32[None, :, 3:] - o[:, None, :]) * inv[:, None, :]
+        t2 = (b32[None, :, :3] + b32[None, :, 3:] - o[:, None, :]) * inv[:, None, :]
+    tn = np.nanmax(np.minimum(t1, t2), axis=2)
+    tf = np.nanmin(np.maximum(t1, t2), axis=2)
+    enters = ((tf >= np.maximum(tn, 0.0))).any(axis=0)
+    assert not (enters & ~breach).any(), (case, np.nonzero(enters & ~breach)[0][:5])
+    if cull and hi - lo <= 7 and aperture < 0.5 * scale:
+        assert sreach.mean() < 0.6 and breach.mean() < 0.7, (case, sreach.mean(), breach.mean())  # it does cull

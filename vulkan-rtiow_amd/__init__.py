@@ -8,4 +8,4 @@ module `vulkan_rtiow_amd` at the repo root (or importlib.import_module).
 """
 from . import api  # noqa: F401
 from .api import *  # noqa: F401,F403
-from .api import Context, MultiContext, RtError, load_library, multi_selftest_host  # noqa: F401
+from .api import Context, MultiContext, RtError, cone_selftest_host, load_library, multi_selftest_host  # noqa: F401

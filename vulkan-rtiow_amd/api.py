@@ -101,6 +101,8 @@ SIGNATURES = {
     "rtMultiTransport": (C.c_char_p, [_VP]),
     "rtMultiGetLastError": (C.c_char_p, [_VP]),
     "rtMultiSelfTestHost": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _VP]),
+    "rtConeSelfTestHost": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _VP, C.c_float, _VP, C.c_uint32,
+                                     _VP, C.c_uint32, _VP, _VP]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -396,3 +398,20 @@ def multi_selftest_host(full: np.ndarray, row_block: int, n_tiles: int) -> np.nd
     if code != RT_OK:
         raise RtError(code, "rtMultiSelfTestHost", (lib.rtMultiGetLastError(None) or b"").decode())
     return out
+
+
+def cone_selftest_host(cam: RtCamera, width: int, height: int, pix_lo: int, pix_hi: int, range_center, range_rmax: float,
+                       spheres: np.ndarray, boxes: np.ndarray):
+    """rtConeSelfTestHost: the primary pass's cull (the kernels' own functions, compiled for the host) for the span of
+    pixels pix_lo..pix_hi of one row: (cull is on?, per-sphere reach flags, per-box reach flags).  No GPU involved."""
+    lib = load_library()
+    spheres = np.ascontiguousarray(spheres, SPHERE_DTYPE)
+    boxes = np.ascontiguousarray(boxes, np.float32).reshape(-1, 6)
+    centre = np.ascontiguousarray(range_center, np.float32)
+    sr = np.zeros(len(spheres), np.uint8)
+    br = np.zeros(len(boxes), np.uint8)
+    code = lib.rtConeSelfTestHost(C.byref(cam), width, height, pix_lo, pix_hi, centre.ctypes.data, float(range_rmax),
+                                  spheres.ctypes.data, len(spheres), boxes.ctypes.data, len(boxes), sr.ctypes.data, br.ctypes.data)
+    if code < 0:
+        raise RtError(-code, "rtConeSelfTestHost", (lib.rtGetLastError(None) or b"").decode())
+    return bool(code), sr.astype(bool), br.astype(bool)

@@ -534,6 +534,17 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
     return RT_OK;
 }
 
+int rtConeSelfTestHost(const RtCamera* cam, uint32_t width, uint32_t height, uint32_t pix_lo, uint32_t pix_hi,
+                       const float* range_center, float range_rmax, const RtSphere* spheres, uint32_t n_spheres,
+                       const float* boxes, uint32_t n_boxes, uint8_t* sphere_reach, uint8_t* box_reach) {
+    if (!cam || !range_center || (n_spheres && (!spheres || !sphere_reach)) || (n_boxes && (!boxes || !box_reach)))
+        return -fail(nullptr, RT_ERR_INVALID, "rtConeSelfTestHost: null argument");
+    if (width < 2 || height < 2 || pix_lo > pix_hi || pix_hi / width != pix_lo / width || pix_hi / width >= height)
+        return -fail(nullptr, RT_ERR_INVALID, "rtConeSelfTestHost: the span must lie in one row of the image");
+    return rtiow::cone_selftest_host(*cam, width, height, pix_lo, pix_hi, range_center, range_rmax, spheres, n_spheres, boxes,
+                                     n_boxes, sphere_reach, box_reach);
+}
+
 int rtGetLastKernel(RtContext* ctx, uint32_t* kernel_out) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rtGetLastKernel: ctx is null");
     if (!kernel_out) return fail(ctx, RT_ERR_INVALID, "rtGetLastKernel: kernel_out is null");

@@ -134,6 +134,10 @@ enum : uint32_t {
 };
 
 hipError_t launch_ch(const ChArgs& a, hipStream_t stream);
+// the primary pass's cone cull run on the host (rtConeSelfTestHost): see rtiow_kernels.hip
+int cone_selftest_host(const RtCamera& cam, uint32_t width, uint32_t height, uint32_t pix_lo, uint32_t pix_hi,
+                       const float* range_center, float range_rmax, const RtSphere* spheres, uint32_t n_spheres,
+                       const float* boxes, uint32_t n_boxes, uint8_t* sphere_reach, uint8_t* box_reach);
 // `resolved` receives the variant that was launched (KERNEL_DEFAULT resolves to one of the others)
 hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, int num_cus,
                        hipStream_t stream, uint32_t* resolved);

@@ -32,13 +32,14 @@ namespace rtiow {
 namespace {
 
 #define DI __device__ __forceinline__
+#define HDI __host__ __device__ __forceinline__  // (also run on the host: rtConeSelfTestHost)
 
 struct f3 {
     float x, y, z;
 };
 
 DI f3 mk(float x, float y, float z) { return f3{x, y, z}; }
-DI float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+HDI float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 DI float dot3(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 DI f3 unit3(f3 a) {
     const float k = 1.0f / __builtin_sqrtf(dot3(a, a));
@@ -95,7 +96,7 @@ DI uint32_t close_pixel(const PathArgs& a, uint32_t local_pix, unsigned long lon
     return resolve_pixel(sr, sg, sb, a.sample_offset + a.spp, a.quantiser);
 }
 
-DI uint32_t tile_global_row(uint32_t lr, uint32_t row_block, uint32_t rank, uint32_t count) {
+HDI uint32_t tile_global_row(uint32_t lr, uint32_t row_block, uint32_t rank, uint32_t count) {
     if (count <= 1) return lr;
     return ((lr / row_block) * count + rank) * row_block + lr % row_block;
 }
@@ -768,9 +769,13 @@ DI uint32_t wave_inclusive_sum(uint32_t v) {
     return v;
 }
 
-DI float slab_rcp(float d) {  // reciprocal of a direction component kept away from zero (finite slabs, no NaN)
+HDI float slab_rcp(float d) {  // reciprocal of a direction component kept away from zero (finite slabs, no NaN)
     const float c = __builtin_fabsf(d) < 1e-18f ? __builtin_copysignf(1e-18f, d) : d;
-    return __builtin_amdgcn_rcpf(c);
+#ifdef __HIP_DEVICE_COMPILE__
+    return __builtin_amdgcn_rcpf(c);  // (v_rcp_f32, 1 ulp: the tests it feeds only cull, with margins far above that)
+#else
+    return 1.0f / c;
+#endif
 }
 
 // Per-wave LDS of the clustered trace: the per-ray result keys, the (ray, cluster) work list of phase 2
@@ -785,7 +790,7 @@ DI void keep_b128(const float4& v) { asm volatile("" ::"v"(v.w)); }
 
 // slab test of one box (centre, half extent) against a ray given by 1/d, -o/d: sign bit of the result
 // set = the ray leaves the box before it enters it (or before its origin)
-DI float slab_gap(const float4& mid, const float4& half, float ix, float iy, float iz, float ax, float ay, float az) {
+HDI float slab_gap(const float4& mid, const float4& half, float ix, float iy, float iz, float ax, float ay, float az) {
     const float tcx = fma_(mid.x, ix, ax);
     const float tcy = fma_(mid.y, iy, ay);
     const float tcz = fma_(mid.z, iz, az);
@@ -1407,7 +1412,7 @@ struct ConeAxis {  // per lane: the cone of the span this half of the wave looks
     bool all;                      // degenerate cone: no cull
 };
 
-DI ConeAxis cone_of_span(const PathArgs& a, const PersistArgs& g, uint32_t pix_lo, uint32_t pix_hi) {
+HDI ConeAxis cone_of_span(const PathArgs& a, const PersistArgs& g, uint32_t pix_lo, uint32_t pix_hi) {
     const RtCamera& c = a.cam;
     const uint32_t lr = pix_lo / a.width;
     const uint32_t i_lo = pix_lo - lr * a.width, i_hi = i_lo + (pix_hi - pix_lo);
@@ -1437,7 +1442,7 @@ DI ConeAxis cone_of_span(const PathArgs& a, const PersistArgs& g, uint32_t pix_l
     return o;
 }
 
-DI bool cone_reaches(const PathArgs& a, const PersistArgs& g, const ConeAxis& c, const float4& mid, const float4& half) {
+HDI bool cone_reaches(const PathArgs& a, const PersistArgs& g, const ConeAxis& c, const float4& mid, const float4& half) {
     const float ex = mid.x - a.cam.origin[0], ey = mid.y - a.cam.origin[1], ez = mid.z - a.cam.origin[2];
     const float proj = fma_(ez, c.dnz, fma_(ey, c.dny, ex * c.dnx));
     const float s_far = ((proj > 0.0f ? proj : 0.0f) + ((half.x + half.y) + half.z) + g.lens_rho) * c.inv1mk;
@@ -1466,7 +1471,7 @@ DI uint32_t cone_mask(const PathArgs& a, const PersistArgs& g, const float4* box
 // within sqrt(r^2 + 64 eps |oc|^2) of the centre, and |oc| <= |e| + rho_L for a camera ray; the distance of the centre
 // from the axis comes from the cross product (no cancellation: its error is a few eps |e|, against the absolute margin of
 // 2^-16 of the coordinate range).  In front of the camera the axis counts as a line, behind it as the point O.
-DI bool cone_reaches_sphere(const PathArgs& a, const PersistArgs& g, const ConeAxis& c, const float4& s) {
+HDI bool cone_reaches_sphere(const PathArgs& a, const PersistArgs& g, const ConeAxis& c, const float4& s) {
     const float ex = s.x - a.cam.origin[0], ey = s.y - a.cam.origin[1], ez = s.z - a.cam.origin[2];
     const float proj = fma_(ez, c.dnz, fma_(ey, c.dny, ex * c.dnx));
     const float ee = fma_(ez, ez, fma_(ey, ey, ex * ex));
@@ -2458,6 +2463,68 @@ hipError_t launch_ch(const ChArgs& a, hipStream_t stream) {
 static bool use_persistent(uint32_t kernel) { return kernel != KERNEL_PIXEL; }
 constexpr uint32_t kClusteredFrom = 64;  // spheres; below, boxes + one cluster cost more than the flat scan
 
+
+// Host side of the primary pass's cone cull (see "The primary pass"): the bounds and margins cone_of_span / cone_reaches /
+// cone_reaches_sphere work with, in double.  False: no cull for this camera (degenerate image, non-finite camera, or a
+// lens that leaves the range the cluster boxes were inflated for).
+static bool cone_setup(const PathArgs& a, PersistArgs& g) {
+    const RtCamera& c = a.cam;
+    auto norm2 = [](const float* v) { return double(v[0]) * v[0] + double(v[1]) * v[1] + double(v[2]) * v[2]; };
+    const double uu = norm2(c.u), vv = norm2(c.v);
+    const double uv = double(c.u[0]) * c.v[0] + double(c.u[1]) * c.v[1] + double(c.u[2]) * c.v[2];
+    // |x u + y v| <= sigma_max |(x, y)|, and the lens sample has |(x, y)| <= lens_radius
+    const double sigma = std::sqrt(0.5 * (uu + vv) + 0.5 * std::sqrt((uu - vv) * (uu - vv) + 4.0 * uv * uv));
+    const double lens = c.lens_radius > 0.0f ? double(c.lens_radius) * sigma * (1.0 + 1.0 / 256.0) : 0.0;
+    g.lens_rho = static_cast<float>(lens);
+    g.h_len = static_cast<float>(std::sqrt(norm2(c.horizontal)) * (1.0 + 1.0 / 64.0));
+    g.v_len = static_cast<float>(std::sqrt(norm2(c.vertical)) * (1.0 + 1.0 / 64.0));
+    double cmax = 0.0, omax = 0.0, dist2 = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        cmax = std::max(cmax, std::fabs(double(a.ccenter[k])));
+        omax = std::max(omax, std::fabs(double(c.origin[k])));
+        dist2 += (double(c.origin[k]) - a.ccenter[k]) * (double(c.origin[k]) - a.ccenter[k]);
+    }
+    const double rmax = std::sqrt(double(a.crmax2));
+    g.abs_margin = static_cast<float>((cmax + omax + 1.5 * rmax) / 65536.0);
+    const bool finite = std::isfinite(lens) && std::isfinite(g.h_len) && std::isfinite(g.v_len) && std::isfinite(g.abs_margin) &&
+                        std::isfinite(dist2);
+    // (the boxes hold for ray origins within rmax of the scene's centre; rtRender re-boxes for a camera beyond 0.95 rmax)
+    const bool in_range = std::sqrt(dist2) + lens <= 0.97 * rmax;
+    return finite && in_range && a.width >= 2u && a.height >= 2u;
+}
+
+// The cone cull on the host, for the CPU test of its conservativeness (tests/test_host_logic.py): the very functions the
+// primary pass runs, for the span of pixels pix_lo..pix_hi (one row) of a width x height image -- which of the spheres
+// {cx, cy, cz, radius} and of the boxes {centre xyz, half extent xyz} the cones of the span may reach.  Returns 0 when
+// the cull is off for this camera (everything is then reached).
+int cone_selftest_host(const RtCamera& cam, uint32_t width, uint32_t height, uint32_t pix_lo, uint32_t pix_hi,
+                       const float* range_center, float range_rmax, const RtSphere* spheres, uint32_t n_spheres,
+                       const float* boxes, uint32_t n_boxes, uint8_t* sphere_reach, uint8_t* box_reach) {
+    PathArgs a{};
+    a.cam = cam;
+    a.width = width;
+    a.height = height;
+    a.inv_wm1 = 1.0f / static_cast<float>(width - 1u);
+    a.inv_hm1 = 1.0f / static_cast<float>(height - 1u);
+    a.row_block = 1u;
+    a.tile_count = 1u;
+    for (int k = 0; k < 3; ++k) a.ccenter[k] = range_center[k];
+    a.crmax2 = range_rmax * range_rmax;
+    PersistArgs g{};
+    const bool cull = cone_setup(a, g);
+    const ConeAxis c = cull ? cone_of_span(a, g, pix_lo, pix_hi) : ConeAxis{};
+    for (uint32_t i = 0; i < n_spheres; ++i) {
+        const float4 s = make_float4(spheres[i].cx, spheres[i].cy, spheres[i].cz, spheres[i].radius * spheres[i].radius);
+        sphere_reach[i] = !cull || cone_reaches_sphere(a, g, c, s) ? 1u : 0u;
+    }
+    for (uint32_t i = 0; i < n_boxes; ++i) {
+        const float4 mid = make_float4(boxes[6u * i], boxes[6u * i + 1u], boxes[6u * i + 2u], 0.0f);
+        const float4 half = make_float4(boxes[6u * i + 3u], boxes[6u * i + 4u], boxes[6u * i + 5u], 0.0f);
+        box_reach[i] = !cull || cone_reaches(a, g, c, mid, half) ? 1u : 0u;
+    }
+    return cull ? 1 : 0;
+}
+
 hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take, int num_cus,
                        hipStream_t stream, uint32_t* resolved) {
     PathArgs a = args;
@@ -2556,32 +2623,10 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     g.pass_cap = g.pass_keep + item_bytes / kPassRecBytes;
     if (g.pass_cap > 64u) g.pass_cap = 64u;
     if (accel) {
-        // the cone cull of the primary pass (see "The primary pass"): bounds and margins, in double
-        const RtCamera& c = a.cam;
-        auto norm2 = [](const float* v) { return double(v[0]) * v[0] + double(v[1]) * v[1] + double(v[2]) * v[2]; };
-        const double uu = norm2(c.u), vv = norm2(c.v);
-        const double uv = double(c.u[0]) * c.v[0] + double(c.u[1]) * c.v[1] + double(c.u[2]) * c.v[2];
-        // |x u + y v| <= sigma_max |(x, y)|, and the lens sample has |(x, y)| <= lens_radius
-        const double sigma = std::sqrt(0.5 * (uu + vv) + 0.5 * std::sqrt((uu - vv) * (uu - vv) + 4.0 * uv * uv));
-        const double lens = c.lens_radius > 0.0f ? double(c.lens_radius) * sigma * (1.0 + 1.0 / 256.0) : 0.0;
-        g.lens_rho = static_cast<float>(lens);
-        g.h_len = static_cast<float>(std::sqrt(norm2(c.horizontal)) * (1.0 + 1.0 / 64.0));
-        g.v_len = static_cast<float>(std::sqrt(norm2(c.vertical)) * (1.0 + 1.0 / 64.0));
-        double cmax = 0.0, omax = 0.0, dist2 = 0.0;
-        for (int k = 0; k < 3; ++k) {
-            cmax = std::max(cmax, std::fabs(double(a.ccenter[k])));
-            omax = std::max(omax, std::fabs(double(c.origin[k])));
-            dist2 += (double(c.origin[k]) - a.ccenter[k]) * (double(c.origin[k]) - a.ccenter[k]);
-        }
-        const double rmax = std::sqrt(double(a.crmax2));
-        g.abs_margin = static_cast<float>((cmax + omax + 1.5 * rmax) / 65536.0);
-        const bool finite = std::isfinite(lens) && std::isfinite(g.h_len) && std::isfinite(g.v_len) && std::isfinite(g.abs_margin) &&
-                            std::isfinite(dist2);
-        // (the boxes hold for ray origins within rmax of the scene's centre; rtRender re-boxes for a camera beyond 0.95 rmax)
-        const bool in_range = std::sqrt(dist2) + lens <= 0.97 * rmax;
+        const bool cull = cone_setup(a, g);
         g.use_pass = kernel == KERNEL_CLUSTERED_PASS ||
                      a.spp >= (getenv("RTIOW_DEBUG_PASS_MIN_SPP") ? strtoul(getenv("RTIOW_DEBUG_PASS_MIN_SPP"), nullptr, 10) : kPassMinSpp) ? 1u : 0u;
-        g.primary_all = (finite && in_range && a.width >= 2u && a.height >= 2u && !getenv("RTIOW_DEBUG_NO_CONE")) ? 0u : 1u;
+        g.primary_all = (cull && !getenv("RTIOW_DEBUG_NO_CONE")) ? 0u : 1u;
     }
     if (threads == 0u) return hipErrorInvalidValue;  // rtSetScene's sphere limit keeps this from happening
     // persistent grid: fill the chip once; never more slots than samples
