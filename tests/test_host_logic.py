@@ -243,17 +243,19 @@ def test_clustered_kernel_keeps_three_waves_per_simd():
         assert v <= 168, (k, v)
 
 
-def _camera_rays(V, cam, width, height, pix_lo, pix_hi, n, rng):
-    """n camera rays of the span pix_lo..pix_hi as camera_path samples them (float64; rtiow_kernels.hip)."""
+def _camera_rays(V, cam, width, height, pix_lo, pix_hi, n, rng, edge=False):
+    """n camera rays of the span pix_lo..pix_hi as camera_path samples them (float64; rtiow_kernels.hip); edge: only the
+    outermost ones -- corners of the span's first and last pixel, rim of the lens."""
     c = {k: np.array(getattr(cam, k), np.float64) for k in ("origin", "lower_left", "horizontal", "vertical", "u", "v")}
-    pix = rng.integers(pix_lo, pix_hi + 1, n)
+    pix = rng.choice([pix_lo, pix_hi], n) if edge else rng.integers(pix_lo, pix_hi + 1, n)
     i, j = pix % width, pix // width
     # the corners and edges of the pixel as well as its inside, the rim of the lens as well as its disk
-    xi = np.where(rng.random(n) < 0.3, rng.integers(0, 2, n).astype(float), rng.random(n))
-    eta = np.where(rng.random(n) < 0.3, rng.integers(0, 2, n).astype(float), rng.random(n))
+    p_edge = 1.0 if edge else 0.3
+    xi = np.where(rng.random(n) < p_edge, rng.integers(0, 2, n).astype(float), rng.random(n))
+    eta = np.where(rng.random(n) < p_edge, rng.integers(0, 2, n).astype(float), rng.random(n))
     u = (i + xi) / (width - 1)
     v = (j + eta) / (height - 1)
-    r = np.where(rng.random(n) < 0.3, 1.0, np.sqrt(rng.random(n))) * float(cam.lens_radius)
+    r = np.where(rng.random(n) < p_edge, 1.0, np.sqrt(rng.random(n))) * float(cam.lens_radius)
     phi = rng.random(n) * 2 * np.pi
     off = (r * np.cos(phi))[:, None] * c["u"] + (r * np.sin(phi))[:, None] * c["v"]
     o = c["origin"] + off
@@ -288,8 +290,20 @@ def test_primary_pass_cone_cull_is_conservative(case):
     hi = min(lo + int(rng.choice([0, 0, 1, 7, 40])), (row + 1) * width - 1)
     centre = np.zeros(3, np.float32)
     rmax = 2.0 * float(np.linalg.norm([16, 16, 16])) * scale + 2.0 * float(np.linalg.norm(frm))   # the camera is in range
+    # ... and tiny spheres ON the outermost rays of the span (pixel corners, rim of the lens), at all distances: the
+    # sharpest probes of the footprint and lens bounds (a footprint bound 30 % short fails here)
+    ob, db = _camera_rays(V, cam, width, height, lo, hi, 96, rng, edge=True)
+    tb = rng.uniform(0.05, 3.0, 96) * focus
+    edge = np.zeros(96, V.SPHERE_DTYPE)
+    pb = ob + tb[:, None] * db
+    edge["cx"], edge["cy"], edge["cz"] = pb[:, 0], pb[:, 1], pb[:, 2]
+    edge["radius"] = 1e-4 * tb
+    sph = np.concatenate([sph, edge])
     cull, sreach, breach = V.cone_selftest_host(cam, width, height, lo, hi, centre, rmax, sph, boxes)
+    assert sreach[n:].all(), (case, np.nonzero(~sreach[n:])[0][:5])
     o, d = _camera_rays(V, cam, width, height, lo, hi, 6000, rng)
+    sph = sph[:n]
+    sreach = sreach[:n]
     c = np.stack([sph["cx"], sph["cy"], sph["cz"]], axis=1).astype(np.float64)
     r2 = sph["radius"].astype(np.float64) ** 2
     oc = o[:, None, :] - c[None, :, :]
