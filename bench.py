@@ -64,9 +64,43 @@ def usable_cores(reported):
     return max(1, n)
 
 
+KERNEL_SOURCES = ("vulkan-rtiow_amd/csrc/rtiow_kernels.hip", "vulkan-rtiow_amd/csrc/rtiow_device.h",
+                  "vulkan-rtiow_amd/csrc/rtiow_rng.h", "vulkan-rtiow_amd/csrc/Makefile")
+
+
+def kernel_source_sha16():
+    """Identity of the kernels a PMC profile was taken with: sha256 over the kernel sources and their build flags.
+    tools/profile_summary.py records it in profiles/r*_pmc.json; figures derived from such a file are printed only
+    while the tree still holds the same kernels (a stale instruction count over a fresh time would be no measurement)."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            hsh.update(f.read())
+    return hsh.hexdigest()[:16]
+
+
+def golden_frame_check(workload, frame_bytes, segments, tile_rows=None):
+    """The timed frame against the oracle's CRC / segment count of the same frame (tests/golden/frame_golden.json, made
+    in the build container by tests/golden/make_frame_golden.py).  "golden": both equal; "DIFFERS": not; None: no golden
+    for this workload."""
+    import zlib
+    try:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "frame_golden.json"))).get(workload)
+    except (OSError, ValueError):
+        gold = None
+    if not gold:
+        return None, None
+    if "crc32" in gold:
+        ok = zlib.crc32(frame_bytes) == gold["crc32"] and int(segments) == gold["segments"]
+        return ("golden" if ok else "DIFFERS"), f"whole frame: crc32 + segment count of the oracle's frame ({gold['segments']} segments)"
+    return None, None
+
+
 def cpu_baseline(V, sph, mat, cam, w, h, spp, depth, chunk, target_s=15.0):
     """Times the CPU oracle (kind "port": the reference has no CPU path) on a bounded sample:
-    every k-th row of the same frame, all host cores, sized for ~target_s seconds."""
+    every k-th row of the same frame, all host cores, sized for ~target_s seconds; and four rows of it on ONE thread
+    (SURVEY 8d / BASELINE.md 3 ask for both)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_bind
     orc = oracle_bind.load()
@@ -88,11 +122,21 @@ def cpu_baseline(V, sph, mat, cam, w, h, spp, depth, chunk, target_s=15.0):
     img, segs = orc.render(sph, mat, cam, prm, nthreads=cores)
     dt = time.perf_counter() - t0
     n_rows = img.shape[0]
+    # one thread: four evenly spread rows (sky, horizon, field, foreground), or fewer if a row takes long
+    rows1 = 4 if per_row * cores * 4 < 2.0 * target_s else 1
+    prm1 = V.make_params(w, h, spp=spp, max_depth=depth, seed=1, chunk_spp=chunk, row_block=1,
+                         tile_rank=0, tile_count=max(1, h // rows1))
+    t0 = time.perf_counter()
+    img1, segs1 = orc.render(sph, mat, cam, prm1, nthreads=1)
+    dt1 = time.perf_counter() - t0
     return {
         "value": n_rows * w * spp * depth / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
         "sample": f"every {stride}th row ({n_rows} of {h} rows) of the same frame at full spp/depth, "
                   f"{dt:.1f} s, OpenMP dynamic over rows",
         "segments_per_s": segs / dt,
+        "one_thread": {"value": img1.shape[0] * w * spp * depth / dt1 / 1e6, "unit": "Mray/s", "cores": 1,
+                       "sample": f"every {max(1, h // rows1)}th row ({img1.shape[0]} of {h} rows) at full spp/depth, {dt1:.1f} s",
+                       "segments_per_s": segs1 / dt1},
     }
 
 
@@ -142,12 +186,22 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
+    D = __import__("importlib").import_module("vulkan-rtiow_amd.dist")
     if world > 1:
+        # A collective that cannot complete ends the job: the timeout turns a hang into an error, and D.fail_loudly
+        # (around everything below) turns an error on any rank into a non-zero exit of that rank at once -- no other
+        # collective is tried in its place (vulkan-rtiow_amd/dist.py).
+        import datetime
+        tmo = datetime.timedelta(seconds=float(os.environ.get("BENCH_COLLECTIVE_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-        D = __import__("importlib").import_module("vulkan-rtiow_amd.dist")
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+    with (D.fail_loudly("bench.py") if world > 1 else __import__("contextlib").nullcontext()):
+        run(args, np, torch, dist, V, D, world, rank, local_rank, backend, dev)
+
+
+def run(args, np, torch, dist, V, D, world, rank, local_rank, backend, dev):
 
     scene, grid_half, w, h, spp, depth = WORKLOADS[args.workload]
     sph, mat, cam = build_scene(V, scene, grid_half, w, h)
@@ -239,8 +293,12 @@ def main():
     else:
         kernel_ms_max, segments = kernel_ms, float(st.segments)
 
-    # N > 1: the last gathered frame against the same frame rendered whole by rank 0 alone (outside the timed region)
-    frame_check = None
+    # N = 1: the last timed frame against the oracle's (CRC-32 + segment count made in the build container); N > 1: the
+    # last gathered frame against the same frame rendered whole by rank 0 alone, and that one against the oracle's.
+    # All of it outside the timed region.
+    frame_check = golden_check = golden_what = None
+    if world == 1 and frame is not None:
+        golden_check, golden_what = golden_frame_check(args.workload, frame.cpu().numpy().tobytes(), st.segments)
     if world > 1 and rank == 0 and frame is not None:
         whole = torch.zeros((h, w), dtype=torch.int32, device=dev)
         wprm = V.make_params(w, h, spp=spp, max_depth=depth, seed=1, chunk_spp=args.chunk_spp, quantiser=V.RT_QUANT_BOOK,
@@ -249,6 +307,7 @@ def main():
             ctx.render_device(cam, wprm, whole.data_ptr(), w * 4, streams[0].cuda_stream)
         torch.cuda.synchronize()
         frame_check = "identical" if bool(torch.equal(frame.to(dev), whole)) else "DIFFERS"
+        golden_check, golden_what = golden_frame_check(args.workload, frame.cpu().numpy().tobytes(), segments)
 
     # The same loop with three frames in flight (three contexts / streams / tile buffers per rank, as the
     # reference's per-swapchain-image fences allow): measured at EVERY N, after the timed region, never `value`.
@@ -303,7 +362,8 @@ def main():
             for tpath in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
                 tj = json.load(open(tpath))
                 if tj.get("workload") == args.workload and tj.get("bench_kernel") == KERNEL_NAMES.get(eff_kernel):
-                    traffic = tj.get("hbm_bytes_per_launch")
+                    if tj.get("kernel_source_sha16") == kernel_source_sha16():  # (of these kernels, not of an earlier round's)
+                        traffic = tj.get("hbm_bytes_per_launch")
                     break
         # VALU issue utilisation of the same kernel from the committed PMC profile (SQ_INSTS_VALU per launch)
         # against the issue rate tools/ubench_valu.hip measures for back-to-back v_fma_f32 on this part
@@ -314,12 +374,15 @@ def main():
             for ppath in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):  # newest round first
                 try:
                     pj = json.load(open(ppath))
+                    if pj.get("kernel_source_sha16") != kernel_source_sha16():
+                        break  # the newest profile is of other kernels than the tree holds: no figure rather than a stale one
                     insts = pj[pmc_name]["SQ_INSTS_VALU"]["mean_per_launch"]
                     valu_issue = {"valu_wave_instructions_per_launch": insts,
                                   "rate": insts / (kernel_ms * 1e-3), "peak": VALU_ISSUE_PEAK, "unit": "wave instructions/s",
                                   "frac": insts / (kernel_ms * 1e-3) / VALU_ISSUE_PEAK,
                                   "lane_occupancy": pj[pmc_name].get("lane_occupancy_valu"),
-                                  "source": "profiles/" + os.path.basename(ppath)}
+                                  "source": "profiles/" + os.path.basename(ppath),
+                                  "kernel_source_sha16": pj.get("kernel_source_sha16")}
                     break
                 except (OSError, KeyError, ValueError):
                     continue
@@ -330,8 +393,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "kernel": KERNEL_NAMES.get(eff_kernel, str(eff_kernel)), "spheres": n, "width": w, "height": h, "spp": spp,
                        "max_depth": depth, "chunk_spp": args.chunk_spp, "seed": 1,
-                       "partition": (f"row-tiles block-cyclic x{args.row_block} over {world} GPUs + RCCL gather"
+                       "partition": (f"row-tiles block-cyclic x{args.row_block} over {world} ranks; frame gathered by {D.transport_label()}"
                                      if world > 1 else "single GPU"),
+                       "backend": (dist.get_backend() if world > 1 else None),
+                       "collective": (D.collective() if world > 1 else None),
+                       "collective_ranks": (dist.get_world_size() if world > 1 else 1),
+                       "rccl_ranks": (dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else 0),
+                       "ranks_on_distinct_gpus": (os.environ.get("BENCH_ONE_DEVICE") != "1") if world > 1 else None,
                        "frames_in_flight": F,
                        "gather": ("side stream: frame k's gather runs beside the rendering of frame k + 1 (two tile buffers)"
                                   if overlap else ("on the rendering stream" if world > 1 else "none (one GPU)")),
@@ -370,6 +438,8 @@ def main():
             out["config"]["three_frames_in_flight"] = inflight3
         if frame_check is not None:
             out["config"]["gathered_frame_vs_single_gpu_frame"] = frame_check
+        out["frame_check"] = golden_check  # "golden": the timed frame IS the oracle's frame (crc32 + segments)
+        out["config"]["frame_check_against"] = golden_what
         if world == 1 and quick:  # the other persistent kernel on the same frame, outside the timed region
             other = 3 if eff_kernel == 2 else 2
             oprm = V.make_params(w, h, spp=spp, max_depth=depth, seed=1, quantiser=V.RT_QUANT_BOOK, kernel=other)

@@ -242,6 +242,12 @@ int rtConeSelfTestHost(const RtCamera* cam, uint32_t width, uint32_t height, uin
                        const float* range_center, float range_rmax, const RtSphere* spheres, uint32_t n_spheres,
                        const float* boxes, uint32_t n_boxes, uint8_t* sphere_reach, uint8_t* box_reach);
 
+/* CPU check of the chunk-order layout (cost-ordered dequeue): for a tile of n_chunks 32-pixel chunks, the words
+ * rtRender allocates for the order (*words_out) and the highest word the kernels index (*max_slot_out), computed with
+ * the functions both sides use; fails if two places of the sequence share a word.  No reference counterpart (the
+ * reference dispatches a fixed grid, RTCHAP06/main.cpp:321). */
+int rtChunkOrderSelfTestHost(uint32_t n_chunks, uint32_t* words_out, uint32_t* max_slot_out);
+
 /* ---- host-side helpers (no GPU needed) ---------------------------------- */
 
 /* RTCHAP06/main.cpp:101-120: width/height -> the UBO the reference fills

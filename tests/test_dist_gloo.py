@@ -23,7 +23,7 @@ def _pattern(rows, width):
 def _worker(rank, world, port, height, width, block, out_path, collective="gather"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    D._collective = collective
+    os.environ["RTIOW_COLLECTIVE"] = collective
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rows = D.tile_rows(height, block, rank, world)
     assert len(rows) == V.tile_row_count(height, block, rank, world)
@@ -55,8 +55,8 @@ def test_gather_reassembles_frame(tmp_path, world, height, width, block):
 
 
 def test_all_gather_form_reassembles_the_same_frame(tmp_path):
-    """The form dist.gather_frame falls back to when the backend refuses a rooted gather (RTIOW_COLLECTIVE=all_gather
-    selects it outright): same padded slots, same de-interleave, same frame."""
+    """RTIOW_COLLECTIVE=all_gather (an explicit choice, never a fallback): same padded slots, same de-interleave,
+    same frame."""
     world, height, width, block = 3, 41, 11, 4
     out = str(tmp_path / "frame.npy")
     mp.spawn(_worker, args=(world, _free_port(), height, width, block, out, "all_gather"), nprocs=world, join=True)
@@ -67,3 +67,57 @@ def test_single_rank_is_identity():
     t = torch.arange(12, dtype=torch.int32).reshape(3, 4)
     assert D.gather_frame(t, 3, 8, 0, 1) is t
     assert D.tile_rows(5, 2, 0, 1).tolist() == [0, 1, 2, 3, 4]
+
+
+def _failing_worker(rank, world, port, exit_codes_dir):
+    """Rank 1's rooted gather raises (as a refused or failed RCCL call would); rank 0 is left inside its own."""
+    import datetime
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), RTIOW_COLLECTIVE="gather")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=20))
+    calls = {"all_gather": 0}
+    real_all_gather = dist.all_gather_into_tensor
+
+    def counting_all_gather(*a, **k):
+        calls["all_gather"] += 1
+        return real_all_gather(*a, **k)
+
+    dist.all_gather_into_tensor = counting_all_gather
+    if rank == 1:
+        def refused(*a, **k):
+            raise RuntimeError("forced gather failure (test)")
+        dist.gather = refused
+    try:
+        with D.fail_loudly("test frame"):
+            local = torch.zeros((len(D.tile_rows(16, 4, rank, world)), 8), dtype=torch.int32)
+            D.gather_frame(local, 16, 4, rank, world)
+    finally:  # (only reached if fail_loudly did NOT end the process: record that)
+        open(os.path.join(exit_codes_dir, f"survived_{rank}_{calls['all_gather']}"), "w").close()
+
+
+def test_a_failed_gather_ends_every_rank_nonzero_and_never_switches_collective(tmp_path):
+    """a collective error is a non-zero exit on every rank within a timeout -- no hang, and no
+    other collective in its place (round 2's gather_frame caught the error and moved that rank alone to all_gather)."""
+    import multiprocessing
+    import time
+    ctx = multiprocessing.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=90)
+    hung = [p for p in procs if p.is_alive()]
+    for p in hung:
+        p.kill()
+    assert not hung, "a rank was still inside the collective after 90 s"
+    assert [p.exitcode for p in procs][1] == 13, [p.exitcode for p in procs]  # the rank whose gather failed
+    assert procs[0].exitcode not in (0, None), "rank 0 completed a frame its peer never sent"
+    assert not os.listdir(tmp_path), os.listdir(tmp_path)  # nobody got past fail_loudly, nobody called all_gather
+    assert time.time() - t0 < 90
+
+
+def test_unknown_collective_is_refused(monkeypatch):
+    monkeypatch.setenv("RTIOW_COLLECTIVE", "broadcast")
+    with pytest.raises(ValueError):
+        D.collective()

@@ -22,6 +22,16 @@ def test_library_exports_every_declared_symbol():
     assert lib.rtAbiVersion() == 3
 
 
+def test_chunk_order_fits_its_allocation():
+    """the chunk order is stored queue by queue (ceil(n / 8) places per queue), so its last word lies at
+    8 * ceil(n / 8) - 2 or - 1 whatever n % 8 is; rtRender must allocate that, not n words.  The functions checked are
+    the ones rtRender sizes the buffer with and the kernels index it with."""
+    for n in list(range(1, 4100)) + [3750, 30000, 259200, 1 << 20]:
+        words, hi = V.chunk_order_selftest_host(n)
+        assert hi < words, (n, words, hi)
+        assert words == 8 * ((n + 7) // 8)
+
+
 def test_header_is_plain_c_and_links(tmp_path):
     """include/rtiow.h compiles as C99 (plain pointers and sizes, no C++), and a C program that references
     every declared entry point links against librtiow_hip.so — what a cgo / JNI / FFI binding relies on."""
@@ -237,8 +247,9 @@ def test_clustered_kernel_keeps_three_waves_per_simd():
         if m and name and "path_persistent_kernel" in name:
             assert int(m.group(1)) == 0, (name, "spills to scratch")
     # (the small-scene variant <true, true> comes from the second compilation of rtiow_kernels.hip: `make asm` runs both)
-    clustered = {k: v for k, v in seen.items() if re.search(r"path_persistent_kernelILb[01]ELb1EEEv", k)}
-    assert len(clustered) == 2, seen.keys()
+    # <shading records in LDS, clustered, express lane>: <0,1,0> large scenes, <1,1,0> small scenes, <1,1,1> small frames
+    clustered = {k: v for k, v in seen.items() if re.search(r"path_persistent_kernelILb[01]ELb1ELb[01]EEEv", k)}
+    assert len(clustered) == 3, seen.keys()
     for k, v in clustered.items():
         assert v <= 168, (k, v)
 

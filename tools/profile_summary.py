@@ -4,6 +4,8 @@ import collections, csv, glob, json, os, re, shutil, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+from bench import kernel_source_sha16  # identity of the kernels these counters belong to (bench.py checks it)
 out = os.path.join(root, "gpurun_out")
 prof = os.path.join(root, "profiles")
 os.makedirs(prof, exist_ok=True)
@@ -63,11 +65,13 @@ if pk and "FETCH_SIZE" in pmc[pk] and "WRITE_SIZE" in pmc[pk]:
                "kernel": pk, "hbm_bytes_per_launch": bytes_of(pk),
                "fetch_kib_raw": pmc[pk]["FETCH_SIZE"]["mean_per_launch"], "write_kib_raw": pmc[pk]["WRITE_SIZE"]["mean_per_launch"],
                "resolve_kernel_hbm_bytes_per_launch": bytes_of(rk) if rk and "FETCH_SIZE" in pmc[rk] else None,
-               "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reads half of a wide stream)"}
+               "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reads half of a wide stream)",
+               "kernel_source_sha16": kernel_source_sha16()}
     json.dump(traffic, open(os.path.join(prof, f"traffic_{tag}.json"), "w"), indent=1)
 for k, v in pmc.items():  # derived: share of the 64 lanes active in an average vector instruction
     if isinstance(v, dict) and "SQ_THREAD_CYCLES_VALU" in v and "SQ_ACTIVE_INST_VALU" in v:
         v["lane_occupancy_valu"] = v["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"] / (64.0 * max(1.0, v["SQ_ACTIVE_INST_VALU"]["mean_per_launch"]))
+pmc["kernel_source_sha16"] = kernel_source_sha16()
 json.dump(pmc, open(os.path.join(prof, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
 # per-launch durations of the path kernel (the stats csv averages the warm-up launch in: cold caches, natural chunk order)
 kt = one(f"prof_{tag}_stats/**/*_kernel_trace.csv")

@@ -101,6 +101,7 @@ SIGNATURES = {
     "rtMultiTransport": (C.c_char_p, [_VP]),
     "rtMultiGetLastError": (C.c_char_p, [_VP]),
     "rtMultiSelfTestHost": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _VP]),
+    "rtChunkOrderSelfTestHost": (C.c_int, [C.c_uint32, _VP, _VP]),
     "rtConeSelfTestHost": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _VP, C.c_float, _VP, C.c_uint32,
                                      _VP, C.c_uint32, _VP, _VP]),
 }
@@ -398,6 +399,17 @@ def multi_selftest_host(full: np.ndarray, row_block: int, n_tiles: int) -> np.nd
     if code != RT_OK:
         raise RtError(code, "rtMultiSelfTestHost", (lib.rtMultiGetLastError(None) or b"").decode())
     return out
+
+
+def chunk_order_selftest_host(n_chunks: int) -> Tuple[int, int]:
+    """rtChunkOrderSelfTestHost: (words rtRender allocates for the chunk order of n_chunks chunks, highest word the
+    kernels index).  No GPU involved."""
+    lib = load_library()
+    words, hi = C.c_uint32(0), C.c_uint32(0)
+    code = lib.rtChunkOrderSelfTestHost(n_chunks, C.byref(words), C.byref(hi))
+    if code != RT_OK:
+        raise RtError(code, "rtChunkOrderSelfTestHost", (lib.rtGetLastError(None) or b"").decode())
+    return int(words.value), int(hi.value)
 
 
 def cone_selftest_host(cam: RtCamera, width: int, height: int, pix_lo: int, pix_hi: int, range_center, range_rmax: float,

@@ -251,13 +251,12 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
     // progressive accumulation: the accumulators belong to one (size, tile) frame; a new frame starts at
     // sample_offset 0.  (Checked and recorded before the empty-tile return: a rank that owns no rows still
     // follows the sequence of its peers.)
-    uint64_t accum_key = 0;
+    const uint32_t n_chunks = is_ch ? 0u : rtiow::chunk_count(rows, W);
+    const RtFrameShape shape{W, H, rblock, tcount > 1 ? prm->tile_rank : 0u, tcount, n_chunks};
     if (!is_ch && prm->accumulate) {
-        accum_key = (uint64_t(W) << 40) ^ (uint64_t(H) << 20) ^ (uint64_t(rblock) << 12) ^
-                    (uint64_t(prm->tile_rank) << 6) ^ uint64_t(tcount);
-        if (prm->sample_offset != 0u && (accum_key != ctx->accum_key || prm->sample_offset != ctx->accum_samples))
+        if (prm->sample_offset != 0u && (shape != ctx->accum_shape || prm->sample_offset != ctx->accum_samples))
             return fail(ctx, RT_ERR_STATE, "rtRender: accumulate continues a different frame or sample count");
-        ctx->accum_key = accum_key;
+        ctx->accum_shape = shape;
         ctx->accum_samples = prm->sample_offset + prm->spp;
     }
     if (rows == 0) return RT_OK;
@@ -358,21 +357,20 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
 #else
         const bool ordered = kernel != rtiow::KERNEL_PIXEL && !getenv("RTIOW_DEBUG_NO_ORDER");  // (tuning only)
 #endif
-        const uint32_t n_chunks = rtiow::chunk_count(rows, W);
         bool collect = false;
         if (ordered) {
-            const uint64_t okey = ((uint64_t(W) << 40) ^ (uint64_t(H) << 20) ^ (uint64_t(rblock) << 12) ^
-                                   (uint64_t(prm->tile_rank) << 6) ^ uint64_t(tcount)) + 1u;
-            const bool fresh = okey != ctx->order_key || ctx->chunk_cost_bytes < size_t(n_chunks) * 8u ||
-                               ctx->chunk_order_bytes < size_t(n_chunks) * 4u;
+            // (the order is stored queue by queue, ceil(n / 8) places per queue: rtiow::chunk_order_words)
+            const size_t order_bytes = size_t(rtiow::chunk_order_words(n_chunks)) * 4u;
+            const bool fresh = shape != ctx->order_shape || ctx->chunk_cost_bytes < size_t(n_chunks) * 8u ||
+                               ctx->chunk_order_bytes < order_bytes;
             int rc = ensure_bytes(ctx, reinterpret_cast<void**>(&ctx->d_chunk_cost), &ctx->chunk_cost_bytes, size_t(n_chunks) * 8u);
             if (rc == RT_OK)
-                rc = ensure_bytes(ctx, reinterpret_cast<void**>(&ctx->d_chunk_order), &ctx->chunk_order_bytes, size_t(n_chunks) * 4u);
+                rc = ensure_bytes(ctx, reinterpret_cast<void**>(&ctx->d_chunk_order), &ctx->chunk_order_bytes, order_bytes);
             if (rc != RT_OK) return rc;
             if (fresh) {
                 RT_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, size_t(n_chunks) * 8u, stream));
                 ctx->order_valid = false;
-                ctx->order_key = okey;
+                ctx->order_shape = shape;
                 ctx->order_frames = 0;
             }
             // The first two frames of a shape report their costs and have them sorted (the second one runs in the order
@@ -543,6 +541,24 @@ int rtConeSelfTestHost(const RtCamera* cam, uint32_t width, uint32_t height, uin
         return -fail(nullptr, RT_ERR_INVALID, "rtConeSelfTestHost: the span must lie in one row of the image");
     return rtiow::cone_selftest_host(*cam, width, height, pix_lo, pix_hi, range_center, range_rmax, spheres, n_spheres, boxes,
                                      n_boxes, sphere_reach, box_reach);
+}
+
+int rtChunkOrderSelfTestHost(uint32_t n_chunks, uint32_t* words_out, uint32_t* max_slot_out) {
+    if (!words_out || !max_slot_out) return fail(nullptr, RT_ERR_INVALID, "rtChunkOrderSelfTestHost: null argument");
+    // the very functions rtRender sizes the buffer with and the kernels index it with
+    *words_out = rtiow::chunk_order_words(n_chunks);
+    uint32_t hi = 0;
+    std::vector<uint8_t> seen(*words_out, 0);
+    for (uint32_t s = 0; s < n_chunks; ++s) {
+        const uint32_t slot = rtiow::chunk_order_slot(s, n_chunks);
+        hi = slot > hi ? slot : hi;
+        if (slot < *words_out) {
+            if (seen[slot]) return fail(nullptr, RT_ERR_STATE, "rtChunkOrderSelfTestHost: two places share a slot");
+            seen[slot] = 1;
+        }
+    }
+    *max_slot_out = hi;
+    return RT_OK;
 }
 
 int rtGetLastKernel(RtContext* ctx, uint32_t* kernel_out) {

@@ -9,6 +9,18 @@
 #include "../../include/rtiow.h"
 #include "rtiow_device.h"
 
+// The (size, tile) a context-held per-frame state belongs to: the progressive accumulators and the chunk order are
+// kept for exactly one of these and start afresh when any field changes (compared field by field: a packed key
+// would alias, e.g. rank 1 of 2 with rank 0 of 66).
+struct RtFrameShape {
+    uint32_t width = 0, height = 0, row_block = 0, tile_rank = 0, tile_count = 0, n_chunks = 0;
+    bool operator==(const RtFrameShape& o) const {
+        return width == o.width && height == o.height && row_block == o.row_block && tile_rank == o.tile_rank &&
+               tile_count == o.tile_count && n_chunks == o.n_chunks;
+    }
+    bool operator!=(const RtFrameShape& o) const { return !(*this == o); }
+};
+
 struct RtContext {
     int device = -1;
     int num_cus = 0;
@@ -43,10 +55,10 @@ struct RtContext {
     size_t chunk_cost_bytes = 0;
     uint32_t* d_chunk_order = nullptr;
     size_t chunk_order_bytes = 0;
-    uint64_t order_key = 0;                 // (size, tile) the order belongs to
+    RtFrameShape order_shape;               // (size, tile) the order belongs to
     bool order_valid = false;
     uint32_t order_frames = 0;              // frames of this shape rendered so far
-    uint64_t accum_key = 0;                 // which frame the accumulators belong to
+    RtFrameShape accum_shape;               // which frame the accumulators belong to
     uint32_t accum_samples = 0;             // samples accumulated so far
     bool have_timing = false;
     bool last_is_ch = false;      // the last render ran a CH05/CH06 kernel (no counters)

@@ -152,6 +152,10 @@ constexpr uint32_t kChunkPixels = RTIOW_CHUNK_PIX;
 inline uint32_t chunk_count(uint32_t local_rows, uint32_t width) {
     return static_cast<uint32_t>((static_cast<unsigned long long>(local_rows) * width + kChunkPixels - 1u) / kChunkPixels);
 }
+// Words of the chunk order: it is stored queue by queue, ceil(n / 8) places for each of the eight queues, so the last
+// place of queue 7 lies at 8 * ceil(n / 8) - 1 whatever n % 8 is.
+__host__ __device__ inline uint32_t chunk_order_words(uint32_t n_chunks) { return 8u * ((n_chunks + 7u) / 8u); }
+__host__ __device__ inline uint32_t chunk_order_slot(uint32_t seq, uint32_t n_chunks) { return (seq & 7u) * ((n_chunks + 7u) / 8u) + (seq >> 3); }
 // order = the chunks by descending cost (ties in no particular order), place s of that sequence stored at
 // (s % 8) * ceil(n / 8) + s / 8 (queue by queue: queue s % 8 takes it as its (s / 8)-th chunk); cost[] is zeroed for the
 // next frame

@@ -488,6 +488,15 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 #define RTIOW_POOL_WORK 40000u
 #endif
 constexpr uint32_t kPoolWork = RTIOW_POOL_WORK;
+#ifndef XDBG_PUSH
+#define XDBG_PUSH 1
+#endif
+#ifndef XDBG_INTAKE
+#define XDBG_INTAKE 1
+#endif
+#ifndef XDBG_BACK
+#define XDBG_BACK 1
+#endif
 #ifndef RTIOW_LONG_FROM
 #define RTIOW_LONG_FROM 12
 #endif
@@ -539,9 +548,13 @@ struct PersistArgs {
     float lens_rho;        // bound of the lens offset |off|, with its margin
     float h_len, v_len;    // |cam.horizontal|, |cam.vertical|, with their margin
     float abs_margin;      // absolute slack of the cone test: 2^-16 of the scene's coordinate range
+    // the express lane of the small-scene clustered kernel (see "The express lane" below)
+    uint32_t express_ticks;  // the last wave of a workgroup turns express once its queue is this close to dry (100 MHz ticks, estimated)
+    uint32_t express_from;   // segments a path must have taken to be handed over
 };
 using PersistentKernelFn = void (*)(PathArgs, PersistArgs);
-PersistentKernelFn small_clustered_kernel();  // path_persistent_kernel<true, true>, from the second compilation of this file
+// path_persistent_kernel<true, true, false>, from the second compilation of this file
+PersistentKernelFn small_clustered_kernel();
 namespace {
 
 DI void examine_candidate(const float4* lds, uint32_t j, uint32_t n, const Path& p, float& best,
@@ -1632,9 +1645,28 @@ constexpr int kAccelMaxThreads = RTIOW_ACCEL_MAX_THREADS;
 // is held there by amdgpu_waves_per_eu, which its 768-thread groups need.  The small-scene variant gets there by itself
 // (tests/test_host_logic.py checks the compiler's report) and is left alone: with the attribute the same source
 // schedules differently and the cover frame takes 4 % longer, 9.82 -> 10.25 ms.)
-template <bool SHADE_LDS, bool ACCEL>
-__global__ __launch_bounds__(ACCEL ? (SHADE_LDS ? RTIOW_SMALL_MAX_THREADS : kAccelMaxThreads) : 1024) __attribute__((amdgpu_waves_per_eu(ACCEL && !SHADE_LDS ? 3 : 1)))
+// ---- The express lane (EXPRESS; small-scene clustered kernel) ------------------------------------------------------
+// A path advances one bounce per iteration of its wave, and an iteration of a full wave takes ~17 us whatever the
+// path: the 0.1 % of paths that bounce fifty times inside a glass ball live 0.85 ms.  On a small frame (one eighth of
+// the cover frame: 1.1 ms of work) every such path born after the first quarter of the frame is still alive when the
+// queues run dry, and the frame ends with every wave nursing two or three of them (tools/timeline.py) -- a fixed cost
+// of ~0.3 ms per frame that no amount of late work explains, and the reason eight tiles did not take an eighth of
+// the time.  So long paths change lanes: when its queue is an estimated express_ticks from dry, the LAST wave of each
+// workgroup stops drawing pixels, lets its own paths run out, and from then on only takes the paths the other waves
+// hand it -- every path of express_from segments or more -- through a ring of records in LDS (its own primary-pass
+// records, idle by then).  It never holds more than kSparseParMax of them, so it runs the path-parallel sparse trace
+// (~4 us per bounce) all the time: a fifty-bounce path then lives 0.2 + 0.15 ms.
+// Which wave traces a path is immaterial to the frame: the pixel's accumulator entry (workgroup LDS, integer sums)
+// is addressed by number, whoever adds the last sample resolves and stores the pixel, and the entry goes back to the
+// wave that owns it through a mask in LDS (xq_returned).  Only pixels that go straight to the frame change lanes
+// (line == 0; a pixel of a line buffer stays with the wave that assembles the line).
+// Ring protocol: xq_free counts the free records (producers take credits with one atomic, give them back if there are
+// too few), xq_tail numbers the places; a record's last word (never 0 when valid) is written after the rest and
+// cleared by the consumer, which takes the valid records from its head on and returns their credits.
+template <bool SHADE_LDS, bool ACCEL, bool EXPRESS = false>
+__global__ __launch_bounds__(ACCEL ? (SHADE_LDS ? RTIOW_SMALL_MAX_THREADS : kAccelMaxThreads) : 1024) __attribute__((amdgpu_waves_per_eu((ACCEL && !SHADE_LDS) || EXPRESS ? 3 : 1)))
 void path_persistent_kernel(PathArgs a, PersistArgs g) {
+    static_assert(!EXPRESS || (SHADE_LDS && ACCEL), "the express lane lives in the small-scene clustered kernel");
     // LDS: sphere list [g.n_pad float4] — the flat list, or (ACCEL) the clustered list's slots, then
     // (ACCEL) the slots' original indices [g.n_pad u32] and the boxes [2 (a.n_clusters + a.n_super) float4];
     // then (SHADE_LDS) two float4 of shading record per sphere; then the accumulator entries of every
@@ -1642,8 +1674,16 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     extern __shared__ float4 lds_spheres[];
     __shared__ unsigned long long wg_sums[3];  // paths, segments, tests of the waves that have left
     __shared__ unsigned int wg_left;           // how many have
+    [[maybe_unused]] __shared__ unsigned long long xq_returned[16];  // (EXPRESS) per wave: accumulator entries the express wave gives back
+    [[maybe_unused]] __shared__ unsigned int xq_tail, xq_free, xq_on;  // (EXPRESS) ring: next place, free records, "hand them over"
     if (threadIdx.x < 3u) wg_sums[threadIdx.x] = 0ull;
     if (threadIdx.x == 3u) wg_left = 0u;
+    if (EXPRESS) {
+        if (threadIdx.x < 16u) xq_returned[threadIdx.x] = 0ull;
+        if (threadIdx.x == 16u) xq_tail = 0u;
+        if (threadIdx.x == 17u) xq_free = 0u;   // (no credits until the express wave opens the ring)
+        if (threadIdx.x == 18u) xq_on = 0u;
+    }
     uint32_t* lds_cidx = reinterpret_cast<uint32_t*>(lds_spheres + g.n_pad);
     float4* lds_cbounds = reinterpret_cast<float4*>(lds_cidx + (ACCEL ? g.n_pad : 0u));
     float4* lds_shade = lds_cbounds + (ACCEL ? 2u * (a.n_clusters + a.n_super) : 0u);
@@ -1702,6 +1742,17 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     uint32_t cur_line = 0u;                  // line buffer of the chunk being handed out, + 1 (0: its pixels go straight to the frame)
     [[maybe_unused]] uint32_t pass_n = 0u;   // (clustered) camera paths waiting in the wave's LDS records for an idle slot
     [[maybe_unused]] bool exhausted = false; // the global queue has been drained
+    // (EXPRESS) the ring is the express wave's own primary-pass records; every wave knows where they are
+    [[maybe_unused]] float4* xq_ring = reinterpret_cast<float4*>(
+        reinterpret_cast<unsigned char*>(lds_acc + waves_in_group * (kWaveAccBytes / 8u)) +
+        waves_in_group * (kWaveLineBytes + wave_item_bytes(a.n_super != 0u)) + (waves_in_group - 1u) * g.pass_keep * kPassRecBytes);
+    [[maybe_unused]] const bool x_wave = EXPRESS && g.express_ticks != 0u && wave_in_group == waves_in_group - 1u;
+    [[maybe_unused]] bool x_mode = false;      // (express wave) no more pixels: it lives on what the others hand it
+    [[maybe_unused]] bool x_open = false;      // ... and has opened the ring
+    [[maybe_unused]] uint32_t x_head = 0u;     // ... its place in it
+    [[maybe_unused]] uint32_t x_rem = ~0u, x_used = 0u;  // pixels left in / taken from the queue at the wave's last fetch
+    [[maybe_unused]] bool entry_starved = false;  // the last hand_out stopped for want of an accumulator entry
+    [[maybe_unused]] const unsigned long long x_t0 = EXPRESS ? wall_clock64() : 0ull;
 #ifdef RTIOW_DEBUG_TIMELINE
     const unsigned long long tl_start = wall_clock64();
     if (lane == 0u) atomicMax(&a.counters->not_t0, ~tl_start);
@@ -1731,9 +1782,21 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         // (fewer than `want` once the queues are dry or the accumulator entries are all in use).
         auto hand_out = [&](uint32_t want, auto&& on_range) -> uint32_t {
             uint32_t served = 0u;  // wave-uniform
+            entry_starved = false;
             while (served < want) {  // one trip per pixel touched (1-2 unless spp is tiny)
                 if (cur_s == a.spp) {  // open the next pixel of the pool
                     if (pool_next == pool_end) {
+                        if constexpr (EXPRESS) {
+                            // (the express wave, at a pool boundary) is the queue an estimated express_ticks from dry?
+                            // time to dry = pixels left * time so far / pixels taken, by the wave's last fetch
+                            if (x_wave && !x_mode && x_rem != ~0u &&
+                                static_cast<unsigned long long>(x_rem) * (wall_clock64() - x_t0) <=
+                                    static_cast<unsigned long long>(g.express_ticks) * x_used) {
+                                x_mode = true;
+                                TL_MARK(tl_dry);
+                            }
+                            if (x_mode) break;  // it draws no more pixels
+                        }
                         // Pool fetch.  The tile's pixels are cut into chunks of kChunkPix consecutive pixels dealt
                         // round-robin to eight queues, one per XCD: a wave draws from the queue of the XCD it runs
                         // on, so the 4-byte stores that complete a 128-byte line of the frame all come from one L2
@@ -1758,6 +1821,10 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                                     pool_xcd = xq;
                                     pool_owned = true;
                                     fetched = true;
+                                    if constexpr (EXPRESS) {
+                                        x_used = got + g.chunk_pool;
+                                        x_rem = vsize - x_used;
+                                    }
 #ifdef RTIOW_DEBUG_TIMELINE
                                     if (xq == 0u && lane == 0u && got * 8u / vsize != (got + g.chunk_pool) * 8u / vsize) {
                                         const unsigned long long t0w = ~__hip_atomic_load(&a.counters->not_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1792,6 +1859,10 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                                     pool_xcd = xq;
                                     pool_owned = false;
                                     fetched = true;
+                                    if constexpr (EXPRESS) {
+                                        x_used = pool_end;
+                                        x_rem = vsize - pool_end;
+                                    }
                                     break;
                                 }
                                 rest_done |= 1u << xq;
@@ -1800,6 +1871,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                         }
                         if (!fetched) {
                             exhausted = true;
+                            if (EXPRESS && x_wave) x_mode = true;  // (dry before the estimate said so: express for the rest of the frame)
                             TL_MARK(tl_dry);
 #ifdef RTIOW_DEBUG_COUNTERS
                             if (!dbg_dry_seen && lane == 0u) {
@@ -1819,7 +1891,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                         cur_seq = seq;
                         // (the order is stored queue by queue, so that an XCD reads its own eighth of it and no more)
                         cur_chunk = a.chunk_order != nullptr
-                                        ? __builtin_amdgcn_readfirstlane(a.chunk_order[pool_xcd * ((n_chunks + 7u) / 8u) + pool_next / kChunkPix])
+                                        ? __builtin_amdgcn_readfirstlane(a.chunk_order[chunk_order_slot(seq, n_chunks)])
                                         : seq;
                         cur_line = 0u;
                         if (pool_owned && free_lines != 0u) {  // (no buffer free: this chunk's pixels go straight to the frame)
@@ -1836,7 +1908,10 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                         ++pool_next;
                         continue;
                     }
-                    if (free_entries == 0ull) break;  // 64 pixels in flight: wait for one to finish
+                    if (free_entries == 0ull) {  // 64 pixels in flight: wait for one to finish
+                        entry_starved = true;
+                        break;
+                    }
                     cur_entry = static_cast<uint32_t>(__builtin_ctzll(free_entries));
                     free_entries &= free_entries - 1ull;
                     cur_pix = pix;
@@ -1935,7 +2010,11 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 const int l = __builtin_ctzll(done_mask);
                 done_mask &= done_mask - 1ull;
                 const uint32_t e = __builtin_amdgcn_readlane(q.entry, l);
-                free_entries |= 1ull << (e % kAccEntries);
+                if (!EXPRESS || e / kAccEntries == wave_in_group) {
+                    free_entries |= 1ull << (e % kAccEntries);
+                } else if (lane == 0u) {  // (the express wave finished another wave's pixel: the entry goes back to its owner)
+                    atomicOr(&xq_returned[e / kAccEntries], 1ull << (e % kAccEntries));
+                }
                 if (__builtin_amdgcn_readlane(static_cast<uint32_t>(line_full), l) != 0u) {
                     const uint32_t line = __builtin_amdgcn_readlane(q.line, l) - 1u;
                     const uint32_t first = __builtin_amdgcn_readlane(q.pix, l) / kChunkPix * kChunkPix;
@@ -1952,6 +2031,14 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             }
         };
         bool any_active = false;
+        if constexpr (EXPRESS) {
+            if (XDBG_BACK && g.express_ticks != 0u) {  // entries of this wave's pixels that were completed by the express wave
+                unsigned long long back = 0ull;
+                if (lane == 0u) back = atomicExch(&xq_returned[wave_in_group], 0ull);
+                free_entries |= static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(back))) |
+                                (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(back >> 32))) << 32);
+            }
+        }
         if constexpr (ACCEL) {
             // Idle slots are filled with camera paths that have already taken their first segment: the primary pass
             // makes up to 64 camera rays at a time (one per lane, consecutive samples of the pool's pixels), traces them
@@ -2126,6 +2213,55 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     left -= granted;
                 }
             }
+            if constexpr (EXPRESS) {
+                if (XDBG_INTAKE && x_mode) {
+                    uint32_t* ring_words = reinterpret_cast<uint32_t*>(xq_ring);
+                    const uint32_t cap = g.pass_keep;  // (a power of two: launch_path)
+                    if (!x_open && pass_n == 0u) {
+                        // its own records are through: they become the ring.  Flags first, then the credits and the
+                        // go-ahead (a wave's LDS operations are performed in order)
+                        if (lane < cap) ring_words[12u * lane + 11u] = 0u;
+                        if (lane == 0u) {
+                            __hip_atomic_store(&xq_free, cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_store(&xq_on, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        x_open = true;
+                    }
+                    if (x_open) {
+                        // intake: never more than kSparseParMax paths in all, so that the wave stays in the sparse trace
+                        const unsigned long long act0 = __ballot(sl[0].active);
+                        const uint32_t live = static_cast<uint32_t>(__popcll(act0)) + static_cast<uint32_t>(__popcll(__ballot(sl[1].active)));
+                        const uint32_t room = live < kSparseParMax ? kSparseParMax - live : 0u;
+                        const bool valid = lane < room && __hip_atomic_load(ring_words + 12u * ((x_head + lane) & (cap - 1u)) + 11u,
+                                                                            __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
+                        const unsigned long long vm = __ballot(valid);
+                        const uint32_t n_take = static_cast<uint32_t>(__builtin_ctzll(~vm));  // the valid records from the head on
+                        if (n_take != 0u) {
+                            const uint32_t k = lane_rank(~act0);
+                            if (!sl[0].active && k < n_take) {
+                                Slot& q = sl[0];
+                                const uint32_t at = (x_head + k) & (cap - 1u);
+                                const float4* rec = xq_ring + 3u * at;
+                                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                                ring_words[12u * at + 11u] = 0u;
+                                q.p.o = mk(r0.x, r0.y, r0.z);
+                                q.p.du = mk(r0.w, r1.x, r1.y);
+                                q.p.att = mk(r1.z, r1.w, r2.x);
+                                q.p.rng = Pcg(__float_as_uint(r2.y));
+                                q.pix = __float_as_uint(r2.z);
+                                const uint32_t packed = __float_as_uint(r2.w);
+                                q.entry = packed & 0x3FFu;
+                                q.line = 0u;
+                                q.depth = packed >> 16;
+                                q.active = true;
+                            }
+                            x_head += n_take;
+                            // (release: the records have been read and their flags cleared before the credits return)
+                            if (lane == 0u) __hip_atomic_fetch_add(&xq_free, n_take, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                }
+            }
             any_active = sl[0].active || sl[1].active;
         } else {
             const unsigned long long idle0 = __ballot(!sl[0].active), idle1 = __ballot(!sl[1].active);
@@ -2159,7 +2295,25 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         }
         // No live path anywhere in the wave: every slot asked and got nothing, so the pool is
         // used up and the global queue drained (an entry shortage needs live paths to exist).
-        if (__ballot(any_active) == 0ull) break;
+        if (__ballot(any_active) == 0ull) {
+            if constexpr (EXPRESS) {
+                if (x_mode) {
+                    // The express wave leaves last: until then the others may hand it paths.  (Their records are in LDS
+                    // before their departure tick: once all have left, one look at the head of the ring settles it.)
+                    const bool alone = __hip_atomic_load(&wg_left, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u == waves_in_group;
+                    const bool waiting = x_open && __hip_atomic_load(reinterpret_cast<uint32_t*>(xq_ring) + 12u * (x_head & (g.pass_keep - 1u)) + 11u,
+                                                                     __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
+                    if (alone && !waiting) break;
+                    if (!waiting) __builtin_amdgcn_s_sleep(16);
+                    continue;
+                }
+                if (g.express_ticks != 0u && entry_starved) {  // all its pixels wait for paths that are with the express wave
+                    __builtin_amdgcn_s_sleep(16);
+                    continue;
+                }
+            }
+            break;
+        }
 #ifdef RTIOW_DEBUG_TIMELINE
         if (tl_dry != 0ull) ++tl_tail_iters;
 #endif
@@ -2230,6 +2384,49 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         }
 #pragma unroll
         for (int r = 0; r < kSlots; ++r) shade_one(sl[r], best[r], best_i[r], best_o[r], rec0[r], rec1[r]);
+        if constexpr (EXPRESS) {
+            // Long paths change lanes (see "The express lane"): from a wave that runs the lock-step trace, to the express wave.
+            if (XDBG_PUSH && g.express_ticks != 0u && !x_wave && live_paths > kSparseMaxAccel) {
+                bool w[kSlots];
+                unsigned long long m[kSlots];
+#pragma unroll
+                for (int r = 0; r < kSlots; ++r) {
+                    w[r] = sl[r].active && sl[r].depth >= g.express_from && sl[r].line == 0u;
+                    m[r] = __ballot(w[r]);
+                }
+                if ((m[0] | m[1]) != 0ull && __hip_atomic_load(&xq_on, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {
+                    constexpr uint32_t kPushMax = 16;  // records one wave asks for at a time
+                    const uint32_t c0 = static_cast<uint32_t>(__popcll(m[0]));
+                    const uint32_t all = c0 + static_cast<uint32_t>(__popcll(m[1]));
+                    const uint32_t cnt = all < kPushMax ? all : kPushMax;
+                    uint32_t base = ~0u;
+                    if (lane == 0u) {  // credits first (given back if there are too few), then the places
+                        const uint32_t had = atomicSub(&xq_free, cnt);
+                        if (static_cast<int32_t>(had) >= static_cast<int32_t>(cnt)) base = atomicAdd(&xq_tail, cnt);
+                        else atomicAdd(&xq_free, cnt);
+                    }
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base != ~0u) {
+#pragma unroll
+                        for (int r = 0; r < kSlots; ++r) {
+                            const uint32_t k = (r == 0 ? 0u : c0) + lane_rank(m[r]);
+                            if (w[r] && k < cnt) {
+                                Slot& q = sl[r];
+                                const uint32_t at = (base + k) & (g.pass_keep - 1u);
+                                float4* rec = xq_ring + 3u * at;
+                                rec[0] = make_float4(q.p.o.x, q.p.o.y, q.p.o.z, q.p.du.x);
+                                rec[1] = make_float4(q.p.du.y, q.p.du.z, q.p.att.x, q.p.att.y);
+                                rec[2] = make_float4(q.p.att.z, __uint_as_float(q.p.rng.state), __uint_as_float(q.pix), 0.0f);
+                                // the word that makes the record valid, after the rest (entry < 1024, depth < 65536: launch_path)
+                                __hip_atomic_store(reinterpret_cast<uint32_t*>(xq_ring) + 12u * at + 11u, q.entry | (q.depth << 16),
+                                                   __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                q.active = false;
+                            }
+                        }
+                    }
+                }
+            }
+        }
         DBG_ADD(dbg_t_refill, t1 - t0);
         DBG_ADD(dbg_t_trace, t2 - t1);
         DBG_ADD(dbg_t_shade, DBG_STAMP() - t2);
@@ -2274,14 +2471,16 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         atomicAdd(&wg_sums[0], static_cast<unsigned long long>(n_paths));
         atomicAdd(&wg_sums[1], static_cast<unsigned long long>(n_segments));
         atomicAdd(&wg_sums[2], tests64);
-        if (atomicAdd(&wg_left, 1u) + 1u == waves_in_group) {
-            atomicAdd(&a.counters->paths, wg_sums[0]);
-            atomicAdd(&a.counters->segments, wg_sums[1]);
-            atomicAdd(&a.counters->tests, wg_sums[2]);
+        // (release / acquire at workgroup scope on the arrival tick, and atomic reads of the sums: the ordering the last
+        // wave relies on is in the code, not in how the LDS happens to execute a wave's operations)
+        if (__hip_atomic_fetch_add(&wg_left, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u == waves_in_group) {
+            atomicAdd(&a.counters->paths, __hip_atomic_load(&wg_sums[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            atomicAdd(&a.counters->segments, __hip_atomic_load(&wg_sums[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            atomicAdd(&a.counters->tests, __hip_atomic_load(&wg_sums[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             // the last workgroup out zeroes the counter block of the NEXT frame (queue heads and all): the frames of a
             // loop then follow each other without a memset in between (with the stats copy moved to rtGetStats, the gap
             // between two path kernels went from 34 to ~10 us)
-            last_group = atomicAdd(&a.counters->wg_done, 1u) + 1u == gridDim.x;
+            last_group = __hip_atomic_fetch_add(&a.counters->wg_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x;
         }
     }
     last_group = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(last_group)) != 0u;
@@ -2408,8 +2607,7 @@ __global__ __launch_bounds__(1024) void order_chunks_kernel(unsigned long long* 
     first[t] = incl - own;
     __syncthreads();
     // place s of the sequence belongs to queue s % 8, which reads it as its (s / 8)-th chunk: stored queue by queue
-    const uint32_t per_queue = (n + 7u) / 8u;
-    auto slot_of = [&](uint32_t seq) { return (seq & 7u) * per_queue + (seq >> 3); };
+    auto slot_of = [&](uint32_t seq) { return chunk_order_slot(seq, n); };  // (< chunk_order_words(n): rtRender allocates that many)
     if (any == 0u) {  // nothing measured: natural order
         for (uint32_t c = t; c < n; c += kOrderBins) order[slot_of(c)] = c;
         return;
@@ -2445,7 +2643,7 @@ __global__ __launch_bounds__(1024) void order_chunks_kernel(unsigned long long* 
 // 8.64 -> 8.40 ms, one eighth of it 1.46 -> 1.41 (interleaved A/B, tools/ab_bench.py).  The large-scene variant spills
 // under that scheduler (C5 1.16 -> 1.22 s) and the flat-list kernels lose 1 % to it, so they stay with the default.
 #ifdef RTIOW_TU_SMALL_CLUSTERED
-PersistentKernelFn small_clustered_kernel() { return path_persistent_kernel<true, true>; }
+PersistentKernelFn small_clustered_kernel() { return path_persistent_kernel<true, true, false>; }
 #else
 
 hipError_t launch_order_chunks(unsigned long long* cost, uint32_t* order, uint32_t n_chunks, uint32_t spp, hipStream_t stream) {
@@ -2543,7 +2741,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // default: the clustered list from kClusteredFrom spheres on (cover scene: 2.1x faster than the
     // flat list; frames are byte-identical either way), the flat list for the handful-of-spheres scenes
     bool accel = kernel == KERNEL_CLUSTERED || kernel == KERNEL_CLUSTERED_PASS || (kernel == KERNEL_DEFAULT && a.n >= kClusteredFrom);
-    constexpr size_t kLdsPerCu = 160u * 1024u - 64u;  // (the kernel's few static __shared__ words come on top of the dynamic part)
+    constexpr size_t kLdsPerCu = 160u * 1024u - 256u;  // (the kernel's static __shared__ words -- up to 176 bytes -- come on top of the dynamic part)
     // The clustered list must fit the LDS beside four waves' buffers.  The very largest scenes give up
     // the super-cluster level first (its boxes and second work list), then fall back to the flat list.
     auto clustered_fits = [&](uint32_t n_super) {
@@ -2581,8 +2779,13 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // large scene with no room for them (C5: one 768-thread group beside 92 KB of list) does without -- its passes then
     // make no more paths than there are idle slots, and the records sit in the two-level work-list area alone
     auto wave_bytes = [&](uint32_t keep) { return kWaveAccBytes + kWaveLineBytes + (accel ? item_bytes + keep * kPassRecBytes : 0u); };
+    // the express lane (long paths handed to the last wave of each workgroup near the end of a frame): the small-scene
+    // clustered kernel; RTIOW_DEBUG_EXPRESS=0 runs the variant compiled without it (tuning / A-B only)
+    const bool express = accel && shade_lds && a.max_depth <= 0xFFFFu && getenv("RTIOW_DEBUG_EXPRESS") && atoi(getenv("RTIOW_DEBUG_EXPRESS")) != 0;
     void (*kernel_fn)(PathArgs, PersistArgs) =
-        accel ? (shade_lds ? small_clustered_kernel() : path_persistent_kernel<false, true>)
+        // (the express variant sits at the 168-register edge: it keeps to it under the default scheduler, held there by
+        // amdgpu_waves_per_eu, and spills 33 registers under iterative-ilp -- so it is compiled here, not in the second pass)
+        accel ? (shade_lds ? (express ? path_persistent_kernel<true, true, true> : small_clustered_kernel()) : path_persistent_kernel<false, true>)
               : (shade_lds ? path_persistent_kernel<true, false> : path_persistent_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsPerCu));
@@ -2629,6 +2832,16 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
         g.primary_all = (cull && !getenv("RTIOW_DEBUG_NO_CONE")) ? 0u : 1u;
     }
     if (threads == 0u) return hipErrorInvalidValue;  // rtSetScene's sphere limit keeps this from happening
+    // The ring of the express lane is the express wave's own block of pass_keep records (a power of two of them); a
+    // workgroup needs a second wave to hand anything over, and entry numbers must fit the record's ten bits.
+    if (express && g.pass_keep >= 16u && (g.pass_keep & (g.pass_keep - 1u)) == 0u && threads >= 128u && threads <= 1024u) {
+        uint32_t us = 450u;
+        if (const char* v = getenv("RTIOW_DEBUG_EXPRESS_US")) us = strtoul(v, nullptr, 10);  // tuning only
+        g.express_ticks = us * 100u;  // wall_clock64 ticks at 100 MHz
+        g.express_from = kLongFrom;
+        if (const char* v = getenv("RTIOW_DEBUG_EXPRESS_FROM")) g.express_from = strtoul(v, nullptr, 10);  // tuning only
+        if (g.express_from < 1u) g.express_from = 1u;
+    }
     // persistent grid: fill the chip once; never more slots than samples
     unsigned long long grid = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256) * per_cu;
     const unsigned long long samples = static_cast<unsigned long long>(g.total_pix) * a.spp;

@@ -327,6 +327,18 @@ int rtMultiRender(RtMulti* m, const RtCamera* cam, const RtParams* params, void*
     hipStream_t root_stream = m->ctx[0]->stream;
     RTM_HIP(m, hipSetDevice(root));
     RTM_HIP(m, hipEventRecord(m->ev_t0, root_stream));
+    // From the first launch on, an error leaves work enqueued on some devices and not on others.  The frame is then
+    // abandoned in a defined state: every context is drained (so that nothing still writes d_gather / d_tile), the
+    // frame counter and ev_t1 are left as the last complete frame set them, and the error goes to the caller.  No
+    // other transport is tried.
+    auto abandon = [&](int code, const std::string& what) {
+        for (size_t g = 0; g < m->ctx.size(); ++g) (void)rtSynchronize(m->ctx[g]);
+        (void)hipSetDevice(root);
+        return mfail(m, code, what);
+    };
+    auto hip_check = [&](hipError_t e, const char* what) {
+        return e == hipSuccess ? std::string() : std::string("rtMultiRender: ") + what + ": " + hipGetErrorString(e);
+    };
     // every device renders its rows on its own context's stream; the root straight into its slot
     for (uint32_t g = 0; g < n; ++g) {
         RtParams p = *params;
@@ -335,13 +347,18 @@ int rtMultiRender(RtMulti* m, const RtCamera* cam, const RtParams* params, void*
         p.tile_count = n;
         uint32_t* tile = g == 0 ? m->d_gather : m->d_tile[g];
         rc = rtRender(m->ctx[g], cam, &p, tile, size_t(W) * 4, /*dst_is_device*/ 1, nullptr);
-        if (rc != RT_OK) return mfail(m, rc, std::string("rtMultiRender: device ") + std::to_string(m->devices[g]) + ": " + rtGetLastError(m->ctx[g]));
+        if (rc != RT_OK)
+            return abandon(rc, std::string("rtMultiRender: device ") + std::to_string(m->devices[g]) + ": " + rtGetLastError(m->ctx[g]));
     }
     // the gather
+    std::string err;
     if (m->transport == Transport::kRccl) {
         int nrc = g_rccl.GroupStart();
-        for (uint32_t g = 0; g < n && nrc == 0; ++g) {
-            RTM_HIP(m, hipSetDevice(m->devices[g]));
+        if (nrc != 0) return abandon(RT_ERR_HIP, std::string("rtMultiRender: ncclGroupStart: ") + g_rccl.GetErrorString(nrc));
+        // (nothing returns between GroupStart and GroupEnd: an open group would swallow every later RCCL call)
+        for (uint32_t g = 0; g < n && nrc == 0 && err.empty(); ++g) {
+            err = hip_check(hipSetDevice(m->devices[g]), "hipSetDevice");
+            if (!err.empty()) break;
             // in place on the root: its tile already sits at recvbuff + 0 * sendcount (rccl.h:733)
             const void* send = g == 0 ? m->d_gather : m->d_tile[g];
             nrc = g_rccl.Gather(send, g == 0 ? m->d_gather : nullptr, slot_words, Rccl::kUint32, /*root*/ 0, m->comms[g],
@@ -349,30 +366,39 @@ int rtMultiRender(RtMulti* m, const RtCamera* cam, const RtParams* params, void*
         }
         const int erc = g_rccl.GroupEnd();
         if (nrc == 0) nrc = erc;
-        if (nrc != 0) return mfail(m, RT_ERR_HIP, std::string("rtMultiRender: ncclGather: ") + g_rccl.GetErrorString(nrc));
+        if (!err.empty()) return abandon(RT_ERR_HIP, err);
+        if (nrc != 0) return abandon(RT_ERR_HIP, std::string("rtMultiRender: ncclGather: ") + g_rccl.GetErrorString(nrc));
     } else {
-        for (uint32_t g = 1; g < n; ++g) {
-            RTM_HIP(m, hipSetDevice(m->devices[g]));
+        for (uint32_t g = 1; g < n && err.empty(); ++g) {
             hipStream_t s = m->ctx[g]->stream;
+            err = hip_check(hipSetDevice(m->devices[g]), "hipSetDevice");
             // (the root may still be reading the previous frame out of the gather buffer)
-            if (m->frames_done != 0) RTM_HIP(m, hipStreamWaitEvent(s, m->ev_t1, 0));
-            RTM_HIP(m, hipMemcpyPeerAsync(m->d_gather + slot_words * g, root, m->d_tile[g], m->devices[g], slot_words * 4, s));
-            RTM_HIP(m, hipEventRecord(m->ev_tile[g], s));
+            if (err.empty() && m->frames_done != 0) err = hip_check(hipStreamWaitEvent(s, m->ev_t1, 0), "hipStreamWaitEvent");
+            if (err.empty())
+                err = hip_check(hipMemcpyPeerAsync(m->d_gather + slot_words * g, root, m->d_tile[g], m->devices[g], slot_words * 4, s),
+                                "hipMemcpyPeerAsync");
+            if (err.empty()) err = hip_check(hipEventRecord(m->ev_tile[g], s), "hipEventRecord");
         }
-        RTM_HIP(m, hipSetDevice(root));
-        for (uint32_t g = 1; g < n; ++g) RTM_HIP(m, hipStreamWaitEvent(root_stream, m->ev_tile[g], 0));
+        if (err.empty()) err = hip_check(hipSetDevice(root), "hipSetDevice");
+        for (uint32_t g = 1; g < n && err.empty(); ++g) err = hip_check(hipStreamWaitEvent(root_stream, m->ev_tile[g], 0), "hipStreamWaitEvent");
+        if (!err.empty()) return abandon(RT_ERR_HIP, err);
     }
     // rows to their places
-    RTM_HIP(m, hipSetDevice(root));
-    hipLaunchKernelGGL(deinterleave_kernel, dim3(n * slot_rows), dim3(256), 0, root_stream, m->d_gather, frame, frame_stride,
-                       W, H, block, n, slot_rows);
-    RTM_HIP(m, hipGetLastError());
-    RTM_HIP(m, hipEventRecord(m->ev_t1, root_stream));
+    err = hip_check(hipSetDevice(root), "hipSetDevice");
+    if (err.empty()) {
+        hipLaunchKernelGGL(deinterleave_kernel, dim3(n * slot_rows), dim3(256), 0, root_stream, m->d_gather, frame, frame_stride,
+                           W, H, block, n, slot_rows);
+        err = hip_check(hipGetLastError(), "deinterleave_kernel");
+    }
+    if (err.empty()) err = hip_check(hipEventRecord(m->ev_t1, root_stream), "hipEventRecord");
+    if (!err.empty()) return abandon(RT_ERR_HIP, err);
     m->have_timing = true;
     ++m->frames_done;
     if (!dst_is_device) {
-        RTM_HIP(m, hipMemcpy2DAsync(dst, dst_pitch, m->d_frame, size_t(W) * 4, size_t(W) * 4, H, hipMemcpyDeviceToHost, root_stream));
-        RTM_HIP(m, hipStreamSynchronize(root_stream));
+        err = hip_check(hipMemcpy2DAsync(dst, dst_pitch, m->d_frame, size_t(W) * 4, size_t(W) * 4, H, hipMemcpyDeviceToHost, root_stream),
+                        "hipMemcpy2DAsync");
+        if (err.empty()) err = hip_check(hipStreamSynchronize(root_stream), "hipStreamSynchronize");
+        if (!err.empty()) return abandon(RT_ERR_HIP, err);
     }
     return RT_OK;
 }

@@ -12,6 +12,9 @@ Pixels do not depend on the partition (RNG keyed by the global pixel index), so
 """
 from __future__ import annotations
 
+import contextlib
+import os
+import sys
 from typing import Optional
 
 import numpy as np
@@ -51,10 +54,31 @@ def _scatter_rows(height: int, row_block: int, world: int, device) -> torch.Tens
     return hit
 
 
+def collective() -> str:
+    """The collective the frame travels by: "gather" (the default: only the root receives) or "all_gather"
+    (RTIOW_COLLECTIVE=all_gather: every rank receives every tile).  An explicit choice, made once per process and the
+    same on every rank; a collective that fails is an error on every rank (see `fail_loudly`), never a reason to try
+    the other one -- on RCCL a rank that switched collectives alone would leave its peers inside the first."""
+    name = os.environ.get("RTIOW_COLLECTIVE", "gather")
+    if name not in ("gather", "all_gather"):
+        raise ValueError(f"RTIOW_COLLECTIVE={name!r}: expected 'gather' or 'all_gather'")
+    return name
+
+
+def transport_label(group=None) -> str:
+    """What actually moves the frame, for bench lines and logs: backend (as torch.distributed names it; "nccl" is RCCL
+    on ROCm), collective, world size."""
+    if not dist.is_available() or not dist.is_initialized():
+        return "single process, no collective"
+    backend = dist.get_backend(group)
+    name = {"nccl": "RCCL (torch backend nccl)", "gloo": "gloo (CPU rehearsal, frames staged through host memory)"}.get(backend, backend)
+    return f"{name} {'ncclGather-style dist.gather to rank 0' if collective() == 'gather' else 'all_gather_into_tensor'}, {dist.get_world_size(group)} ranks"
+
+
 def gather_frame(local: torch.Tensor, height: int, row_block: int, rank: int, world: int,
                  dst: int = 0, group=None) -> Optional[torch.Tensor]:
     """Gathers every rank's packed rows ([rows_r, width] int32, RGBA8 packed) to `dst` and
-    returns the assembled [height, width] frame there (None elsewhere)."""
+    returns the assembled [height, width] frame there (None elsewhere).  Errors of the collective propagate."""
     if world <= 1:
         return local
     # RCCL moves device tensors; a gloo rehearsal (tests, or two ranks sharing one GPU) stages via host
@@ -68,30 +92,37 @@ def gather_frame(local: torch.Tensor, height: int, row_block: int, rank: int, wo
         send = torch.zeros((pad_rows, width), dtype=local.dtype, device=local.device)
         send[: local.shape[0]] = local
     send = send.contiguous()
-    global _collective
-    if _collective == "gather":
-        try:
-            if rank == dst:
-                # one receive buffer [world, pad_rows, width]; one scatter of its rows into the frame
-                # (plus a scratch row that swallows the padding)
-                recv = torch.empty((world, pad_rows, width), dtype=local.dtype, device=local.device)
-                dist.gather(send, gather_list=list(recv.unbind(0)), dst=dst, group=group)
-                return _deinterleave(recv, height, row_block, world)
-            dist.gather(send, gather_list=None, dst=dst, group=group)
-            return None
-        except (RuntimeError, NotImplementedError) as exc:
-            # A backend without a rooted gather refuses the call on every rank alike, before anything is sent: all of
-            # them fall through to the all-gather form together.  (The RCCL gather has not run on hardware yet.)
-            import warnings
-            warnings.warn(f"dist.gather refused ({exc}); using all_gather_into_tensor for the frame")
-            _collective = "all_gather"
+    if collective() == "gather":
+        if rank == dst:
+            # one receive buffer [world, pad_rows, width]; one scatter of its rows into the frame
+            # (plus a scratch row that swallows the padding)
+            recv = torch.empty((world, pad_rows, width), dtype=local.dtype, device=local.device)
+            dist.gather(send, gather_list=list(recv.unbind(0)), dst=dst, group=group)
+            return _deinterleave(recv, height, row_block, world)
+        dist.gather(send, gather_list=None, dst=dst, group=group)
+        return None
     recv = torch.empty((world, pad_rows, width), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(recv.view(world * pad_rows, width), send, group=group)
     return _deinterleave(recv, height, row_block, world) if rank == dst else None
 
 
-# "gather" (the default: only the root receives) or "all_gather" (RTIOW_COLLECTIVE=all_gather, or after a refusal)
-_collective = __import__("os").environ.get("RTIOW_COLLECTIVE", "gather")
+@contextlib.contextmanager
+def fail_loudly(what: str = "multi-GPU frame"):
+    """Wraps the N > 1 part of a program: any exception on this rank is printed with its rank and ends the PROCESS with
+    a non-zero code at once (os._exit: no communicator destructors, which may wait for peers that are themselves stuck
+    in the collective this rank never joined).  The launcher (torch.distributed.run) then tears the other ranks down,
+    and a peer left inside a collective fails on its own once this rank's sockets close or the process group's timeout
+    expires -- it never completes a different collective instead."""
+    try:
+        yield
+    except BaseException as exc:  # noqa: BLE001 (KeyboardInterrupt too: the peers must not be left waiting)
+        import traceback
+        r = os.environ.get("RANK", "?")
+        sys.stderr.write(f"[rank {r}] {what} failed: {type(exc).__name__}: {exc}\n")
+        traceback.print_exc()
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(13)
 
 
 def _deinterleave(recv: torch.Tensor, height: int, row_block: int, world: int) -> torch.Tensor:
