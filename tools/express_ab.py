@@ -10,6 +10,8 @@ def arg(name, default):
 
 configs = arg("--configs", "tile8,full,tile4,tile2,spp1,spp16").split(",")
 variants = [("off", {"RTIOW_DEBUG_EXPRESS": "0"})]
+if "--variant-only" in sys.argv:
+    variants.append(("express kernel, no x wave", {"RTIOW_DEBUG_EXPRESS": "2"}))
 for us in arg("--us", "450").split(","):
     for frm in arg("--from", "12").split(","):
         variants.append((f"on us={us} from={frm}", {"RTIOW_DEBUG_EXPRESS": "1", "RTIOW_DEBUG_EXPRESS_US": us, "RTIOW_DEBUG_EXPRESS_FROM": frm}))

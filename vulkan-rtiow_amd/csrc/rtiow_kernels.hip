@@ -488,15 +488,7 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 #define RTIOW_POOL_WORK 40000u
 #endif
 constexpr uint32_t kPoolWork = RTIOW_POOL_WORK;
-#ifndef XDBG_PUSH
-#define XDBG_PUSH 1
-#endif
-#ifndef XDBG_INTAKE
-#define XDBG_INTAKE 1
-#endif
-#ifndef XDBG_BACK
-#define XDBG_BACK 1
-#endif
+
 #ifndef RTIOW_LONG_FROM
 #define RTIOW_LONG_FROM 12
 #endif
@@ -549,7 +541,7 @@ struct PersistArgs {
     float h_len, v_len;    // |cam.horizontal|, |cam.vertical|, with their margin
     float abs_margin;      // absolute slack of the cone test: 2^-16 of the scene's coordinate range
     // the express lane of the small-scene clustered kernel (see "The express lane" below)
-    uint32_t express_ticks;  // the last wave of a workgroup turns express once its queue is this close to dry (100 MHz ticks, estimated)
+    uint32_t express;        // != 0: the last wave of every workgroup is its express wave
     uint32_t express_from;   // segments a path must have taken to be handed over
 };
 using PersistentKernelFn = void (*)(PathArgs, PersistArgs);
@@ -1645,28 +1637,35 @@ constexpr int kAccelMaxThreads = RTIOW_ACCEL_MAX_THREADS;
 // is held there by amdgpu_waves_per_eu, which its 768-thread groups need.  The small-scene variant gets there by itself
 // (tests/test_host_logic.py checks the compiler's report) and is left alone: with the attribute the same source
 // schedules differently and the cover frame takes 4 % longer, 9.82 -> 10.25 ms.)
-// ---- The express lane (EXPRESS; small-scene clustered kernel) ------------------------------------------------------
+// ---- The express lane (EXPRESS; small-scene clustered kernel, small frames) -----------------------------------------
 // A path advances one bounce per iteration of its wave, and an iteration of a full wave takes ~17 us whatever the
-// path: the 0.1 % of paths that bounce fifty times inside a glass ball live 0.85 ms.  On a small frame (one eighth of
+// path: the 0.09 % of paths that bounce fifty times inside a glass ball live 0.85 ms.  On a small frame (one eighth of
 // the cover frame: 1.1 ms of work) every such path born after the first quarter of the frame is still alive when the
 // queues run dry, and the frame ends with every wave nursing two or three of them (tools/timeline.py) -- a fixed cost
 // of ~0.3 ms per frame that no amount of late work explains, and the reason eight tiles did not take an eighth of
-// the time.  So long paths change lanes: when its queue is an estimated express_ticks from dry, the LAST wave of each
-// workgroup stops drawing pixels, lets its own paths run out, and from then on only takes the paths the other waves
-// hand it -- every path of express_from segments or more -- through a ring of records in LDS (its own primary-pass
-// records, idle by then).  It never holds more than kSparseParMax of them, so it runs the path-parallel sparse trace
-// (~4 us per bounce) all the time: a fifty-bounce path then lives 0.2 + 0.15 ms.
+// the time.  So long paths change lanes.  The EXPRESS variant runs ONE workgroup of twelve waves per CU; its last
+// wave draws no pixels at all: it takes the paths the other eleven hand it -- every path of express_from segments or
+// more (2.5 % of all segments lie beyond the twelfth: tools/path_lengths.py) -- through a ring of records in LDS (the
+// wave's own primary-pass records, which it never uses).  It holds at most kSparseParMax of them, runs the path-parallel
+// sparse trace on them and nothing else (~5 us per bounce), so a fifty-bounce path lives 0.2 + 0.2 ms.
 // Which wave traces a path is immaterial to the frame: the pixel's accumulator entry (workgroup LDS, integer sums)
 // is addressed by number, whoever adds the last sample resolves and stores the pixel, and the entry goes back to the
 // wave that owns it through a mask in LDS (xq_returned).  Only pixels that go straight to the frame change lanes
-// (line == 0; a pixel of a line buffer stays with the wave that assembles the line).
+// (line == 0; a pixel of a line buffer stays with the wave that assembles the line -- small frames have none).
 // Ring protocol: xq_free counts the free records (producers take credits with one atomic, give them back if there are
 // too few), xq_tail numbers the places; a record's last word (never 0 when valid) is written after the rest and
 // cleared by the consumer, which takes the valid records from its head on and returns their credits.
+// The same loop -- sparse trace, shade, nothing else -- is where every other wave ends its frame once the queues are
+// dry and it is down to kSparseParMax paths (no refill attempts, no second slot, no compaction per iteration).
 template <bool SHADE_LDS, bool ACCEL, bool EXPRESS = false>
-__global__ __launch_bounds__(ACCEL ? (SHADE_LDS ? RTIOW_SMALL_MAX_THREADS : kAccelMaxThreads) : 1024) __attribute__((amdgpu_waves_per_eu((ACCEL && !SHADE_LDS) || EXPRESS ? 3 : 1)))
+__global__ __launch_bounds__(ACCEL ? (SHADE_LDS && !EXPRESS ? RTIOW_SMALL_MAX_THREADS : kAccelMaxThreads) : 1024) __attribute__((amdgpu_waves_per_eu((ACCEL && !SHADE_LDS) || EXPRESS ? 3 : 1)))
 void path_persistent_kernel(PathArgs a, PersistArgs g) {
     static_assert(!EXPRESS || (SHADE_LDS && ACCEL), "the express lane lives in the small-scene clustered kernel");
+#ifndef RTIOW_TAIL_LOOP
+#define RTIOW_TAIL_LOOP 0
+#endif
+    // the sparse loop at the end of a wave's frame (see "The express lane"): the express variant, or -DRTIOW_TAIL_LOOP=1
+    constexpr bool kSparseLoop = EXPRESS || (RTIOW_TAIL_LOOP != 0 && SHADE_LDS && ACCEL);
     // LDS: sphere list [g.n_pad float4] — the flat list, or (ACCEL) the clustered list's slots, then
     // (ACCEL) the slots' original indices [g.n_pad u32] and the boxes [2 (a.n_clusters + a.n_super) float4];
     // then (SHADE_LDS) two float4 of shading record per sphere; then the accumulator entries of every
@@ -1675,14 +1674,13 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     __shared__ unsigned long long wg_sums[3];  // paths, segments, tests of the waves that have left
     __shared__ unsigned int wg_left;           // how many have
     [[maybe_unused]] __shared__ unsigned long long xq_returned[16];  // (EXPRESS) per wave: accumulator entries the express wave gives back
-    [[maybe_unused]] __shared__ unsigned int xq_tail, xq_free, xq_on;  // (EXPRESS) ring: next place, free records, "hand them over"
+    [[maybe_unused]] __shared__ unsigned int xq_tail, xq_free;  // (EXPRESS) ring: next place, free records
     if (threadIdx.x < 3u) wg_sums[threadIdx.x] = 0ull;
     if (threadIdx.x == 3u) wg_left = 0u;
     if (EXPRESS) {
         if (threadIdx.x < 16u) xq_returned[threadIdx.x] = 0ull;
         if (threadIdx.x == 16u) xq_tail = 0u;
-        if (threadIdx.x == 17u) xq_free = 0u;   // (no credits until the express wave opens the ring)
-        if (threadIdx.x == 18u) xq_on = 0u;
+        if (threadIdx.x == 17u) xq_free = g.express != 0u ? g.pass_keep : 0u;  // (every record of the ring is free)
     }
     uint32_t* lds_cidx = reinterpret_cast<uint32_t*>(lds_spheres + g.n_pad);
     float4* lds_cbounds = reinterpret_cast<float4*>(lds_cidx + (ACCEL ? g.n_pad : 0u));
@@ -1716,6 +1714,12 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         const float4* src = reinterpret_cast<const float4*>(a.shade);
         for (uint32_t i = threadIdx.x; i < 2u * a.n; i += blockDim.x) lds_shade[i] = src[i];
     }
+    if (EXPRESS && g.express != 0u && threadIdx.x < g.pass_keep) {  // the ring: the last wave's records, all invalid
+        uint32_t* ring_words = reinterpret_cast<uint32_t*>(
+            reinterpret_cast<unsigned char*>(lds_acc + waves_in_group * (kWaveAccBytes / 8u)) +
+            waves_in_group * (kWaveLineBytes + wave_item_bytes(a.n_super != 0u)) + (waves_in_group - 1u) * g.pass_keep * kPassRecBytes);
+        ring_words[12u * threadIdx.x + 11u] = 0u;
+    }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
 
@@ -1746,13 +1750,8 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     [[maybe_unused]] float4* xq_ring = reinterpret_cast<float4*>(
         reinterpret_cast<unsigned char*>(lds_acc + waves_in_group * (kWaveAccBytes / 8u)) +
         waves_in_group * (kWaveLineBytes + wave_item_bytes(a.n_super != 0u)) + (waves_in_group - 1u) * g.pass_keep * kPassRecBytes);
-    [[maybe_unused]] const bool x_wave = EXPRESS && g.express_ticks != 0u && wave_in_group == waves_in_group - 1u;
-    [[maybe_unused]] bool x_mode = false;      // (express wave) no more pixels: it lives on what the others hand it
-    [[maybe_unused]] bool x_open = false;      // ... and has opened the ring
-    [[maybe_unused]] uint32_t x_head = 0u;     // ... its place in it
-    [[maybe_unused]] uint32_t x_rem = ~0u, x_used = 0u;  // pixels left in / taken from the queue at the wave's last fetch
+    [[maybe_unused]] const bool x_wave = EXPRESS && g.express != 0u && wave_in_group == waves_in_group - 1u;
     [[maybe_unused]] bool entry_starved = false;  // the last hand_out stopped for want of an accumulator entry
-    [[maybe_unused]] const unsigned long long x_t0 = EXPRESS ? wall_clock64() : 0ull;
 #ifdef RTIOW_DEBUG_TIMELINE
     const unsigned long long tl_start = wall_clock64();
     if (lane == 0u) atomicMax(&a.counters->not_t0, ~tl_start);
@@ -1773,7 +1772,114 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     unsigned long long dbg_tail_cyc[3] = {0ull, 0ull, 0ull};
 #endif
 
-    for (;;) {
+    // ---- shade (used below, and by the primary pass inside the refill) ------
+    // One segment of the path in q has been traced (best_i < 0: it left the scene).  Miss -> sky radiance into the
+    // pixel's accumulator, hit -> scatter; a path that ends bumps its pixel's counter, the lane that completes a pixel
+    // resolves and stores it.  r0, r1: the hit's shading record when the records are not in LDS.
+    auto shade_one = [&](Slot& q, float hit_t, int hit_slot, uint32_t hit_orig, const float4& r0, const float4& r1) {
+        if (__ballot(q.active) == 0ull) return;  // (sparse iterations keep their paths in slot 0)
+        bool finished = false;
+        if (q.active) {
+            ++n_segments;
+            unsigned long long* acc = lds_acc + q.entry * kAccWords;
+            if (hit_slot < 0) {
+                const f3 rad = sky_radiance(q.p);
+                atomicAdd(acc + 0, to_fixed(rad.x));  // ds_add_u64: order-independent integer sum
+                atomicAdd(acc + 1, to_fixed(rad.y));
+                atomicAdd(acc + 2, to_fixed(rad.z));
+                finished = true;
+            } else {
+                const float4 geo = lds_spheres[hit_slot];
+                ShadeRec m;
+                if (SHADE_LDS) {
+                    const float4 m0 = lds_shade[2u * hit_orig], m1 = lds_shade[2u * hit_orig + 1u];
+                    m.albedo[0] = m0.x; m.albedo[1] = m0.y; m.albedo[2] = m0.z; m.param = m0.w;
+                    m.inv_r = m1.x; m.kind = __float_as_uint(m1.y);
+                } else {
+                    m.albedo[0] = r0.x; m.albedo[1] = r0.y; m.albedo[2] = r0.z; m.param = r0.w;
+                    m.inv_r = r1.x; m.kind = __float_as_uint(r1.y);
+                }
+                if (!scatter(mk(geo.x, geo.y, geo.z), m, hit_t, q.p)) {
+                    finished = true;  // absorbed: radiance 0
+                } else if (++q.depth >= a.max_depth) {
+                    finished = true;  // depth exhausted: radiance 0
+                }
+            }
+        }
+        // A finished sample bumps its pixel's counter; the lane that completes the pixel
+        // resolves it.  All adds to the entry were issued by earlier LDS instructions of
+        // this wave (or serialised within this one), so the sums it reads are final.
+        bool completed = false;
+        bool line_full = false;  // this lane's pixel was the last of a line buffer
+        if (finished) {
+            q.active = false;
+            unsigned long long* acc = lds_acc + q.entry * kAccWords;
+            // low half: samples done; high half: the segments they took (<= 65535 each, <= 65536 samples)
+            // (A long path counts kLongWeight-fold: what ends a frame is not the work of its last chunks but the LENGTH of
+            // the paths born in them -- fifty bounces at one iteration each -- so chunks in which long paths occur are to go
+            // out first whatever their average; the sum only orders the chunks of the next frame.)
+            const uint32_t segs1 = q.depth < 0xFFFEu ? q.depth + 1u : 0xFFFFu;
+            const uint32_t segs = segs1 > kLongFrom ? (segs1 * kLongWeight < 0xFFFFu ? segs1 * kLongWeight : 0xFFFFu) : segs1;
+            const unsigned long long before = atomicAdd(acc + 3, 1ull | (static_cast<unsigned long long>(segs) << 32));
+            if (static_cast<uint32_t>(before) + 1u == a.spp) {
+                completed = true;
+                const uint32_t colour = close_pixel(a, q.pix, acc[0], acc[1], acc[2]);
+                const uint32_t line = q.line;
+                if (line == 0u) {
+                    const uint32_t lr = q.pix / a.width, i = q.pix - lr * a.width;
+                    a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = colour;
+                } else {  // a pixel of a chunk this wave renders alone: into the line buffer
+                    lds_line[(line - 1u) * kChunkPix + q.pix % kChunkPix] = colour;
+                    uint32_t* meta = lds_line_meta + kLineMetaWords * (line - 1u);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(meta + 2), (before >> 32) + segs);  // the chunk's cost, in LDS
+                    const uint32_t done = atomicAdd(meta, 1u);
+                    line_full = done + 1u == meta[1];
+                }
+                // what this pixel cost, for the next frame's chunk order (a global atomic leaves the L2 as a 64-byte
+                // memory-side request: whole chunks sum theirs in LDS and report once, with the line)
+                // ... and of the pixels handed out one by one, every fourth speaks for its neighbours -- unless a long
+                // path ended in this one: those are what the order is for, and too rare to be sampled
+                if (a.chunk_cost != nullptr && line == 0u) {
+                    const unsigned long long cost = (before >> 32) + segs;
+                    if (cost >= static_cast<unsigned long long>(a.spp) * kLongFrom + kLongFrom * kLongWeight)  // (one long path at least)
+                        atomicAdd(a.chunk_cost + q.pix / kChunkPix, cost);
+                    else if ((q.pix & 3u) == 0u)
+                        atomicAdd(a.chunk_cost + q.pix / kChunkPix, 4ull * cost);
+                }
+            }
+        }
+        // Completed pixels (0-2 per iteration): their accumulator entries return to the wave; a pixel that filled
+        // its line buffer has the line stored -- up to 32 consecutive pixels, 128 bytes, the whole line of the
+        // frame in one store.  (A wave's LDS operations are performed in order: the colour written above is there.)
+        unsigned long long done_mask = __ballot(completed);
+        while (done_mask != 0ull) {
+            const int l = __builtin_ctzll(done_mask);
+            done_mask &= done_mask - 1ull;
+            const uint32_t e = __builtin_amdgcn_readlane(q.entry, l);
+            if (!EXPRESS || e / kAccEntries == wave_in_group) {
+                free_entries |= 1ull << (e % kAccEntries);
+            } else if (lane == 0u) {  // (the express wave finished another wave's pixel: the entry goes back to its owner)
+                atomicOr(&xq_returned[e / kAccEntries], 1ull << (e % kAccEntries));
+            }
+            if (__builtin_amdgcn_readlane(static_cast<uint32_t>(line_full), l) != 0u) {
+                const uint32_t line = __builtin_amdgcn_readlane(q.line, l) - 1u;
+                const uint32_t first = __builtin_amdgcn_readlane(q.pix, l) / kChunkPix * kChunkPix;
+                const uint32_t count = g.total_pix - first < kChunkPix ? g.total_pix - first : kChunkPix;
+                if (lane < count) {
+                    const uint32_t pix = first + lane;
+                    const uint32_t lr = pix / a.width, i = pix - lr * a.width;  // (a chunk may run over the end of a row)
+                    a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = lds_line[line * kChunkPix + lane];
+                }
+                if (a.chunk_cost != nullptr && lane == 0u)  // this wave rendered the whole chunk: a plain store
+                    a.chunk_cost[first / kChunkPix] = *reinterpret_cast<const unsigned long long*>(lds_line_meta + kLineMetaWords * line + 2u);
+                free_lines |= 1u << line;
+            }
+        }
+    };
+    // (EXPRESS) the express wave never enters the main loop; the others leave it for the sparse loop below once their
+    // queues are dry and they are down to kSparseParMax paths
+    [[maybe_unused]] bool to_sparse_loop = x_wave;
+    for (; !x_wave;) {
         [[maybe_unused]] const unsigned long long t0 = DBG_STAMP();
         // ---- refill ---------------------------------------------------------
         // Hands out the next `want` samples of the wave's pool, pixel by pixel: on_range(first, n, pixel, entry, sample)
@@ -1786,17 +1892,6 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             while (served < want) {  // one trip per pixel touched (1-2 unless spp is tiny)
                 if (cur_s == a.spp) {  // open the next pixel of the pool
                     if (pool_next == pool_end) {
-                        if constexpr (EXPRESS) {
-                            // (the express wave, at a pool boundary) is the queue an estimated express_ticks from dry?
-                            // time to dry = pixels left * time so far / pixels taken, by the wave's last fetch
-                            if (x_wave && !x_mode && x_rem != ~0u &&
-                                static_cast<unsigned long long>(x_rem) * (wall_clock64() - x_t0) <=
-                                    static_cast<unsigned long long>(g.express_ticks) * x_used) {
-                                x_mode = true;
-                                TL_MARK(tl_dry);
-                            }
-                            if (x_mode) break;  // it draws no more pixels
-                        }
                         // Pool fetch.  The tile's pixels are cut into chunks of kChunkPix consecutive pixels dealt
                         // round-robin to eight queues, one per XCD: a wave draws from the queue of the XCD it runs
                         // on, so the 4-byte stores that complete a 128-byte line of the frame all come from one L2
@@ -1821,10 +1916,6 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                                     pool_xcd = xq;
                                     pool_owned = true;
                                     fetched = true;
-                                    if constexpr (EXPRESS) {
-                                        x_used = got + g.chunk_pool;
-                                        x_rem = vsize - x_used;
-                                    }
 #ifdef RTIOW_DEBUG_TIMELINE
                                     if (xq == 0u && lane == 0u && got * 8u / vsize != (got + g.chunk_pool) * 8u / vsize) {
                                         const unsigned long long t0w = ~__hip_atomic_load(&a.counters->not_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1859,10 +1950,6 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                                     pool_xcd = xq;
                                     pool_owned = false;
                                     fetched = true;
-                                    if constexpr (EXPRESS) {
-                                        x_used = pool_end;
-                                        x_rem = vsize - pool_end;
-                                    }
                                     break;
                                 }
                                 rest_done |= 1u << xq;
@@ -1871,7 +1958,6 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                         }
                         if (!fetched) {
                             exhausted = true;
-                            if (EXPRESS && x_wave) x_mode = true;  // (dry before the estimate said so: express for the rest of the frame)
                             TL_MARK(tl_dry);
 #ifdef RTIOW_DEBUG_COUNTERS
                             if (!dbg_dry_seen && lane == 0u) {
@@ -1926,113 +2012,9 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             }
             return served;
         };
-        // ---- shade (used below, and by the primary pass inside the refill) ------
-        // One segment of the path in q has been traced (best_i < 0: it left the scene).  Miss -> sky radiance into the
-        // pixel's accumulator, hit -> scatter; a path that ends bumps its pixel's counter, the lane that completes a pixel
-        // resolves and stores it.  r0, r1: the hit's shading record when the records are not in LDS.
-        auto shade_one = [&](Slot& q, float hit_t, int hit_slot, uint32_t hit_orig, const float4& r0, const float4& r1) {
-            if (__ballot(q.active) == 0ull) return;  // (sparse iterations keep their paths in slot 0)
-            bool finished = false;
-            if (q.active) {
-                ++n_segments;
-                unsigned long long* acc = lds_acc + q.entry * kAccWords;
-                if (hit_slot < 0) {
-                    const f3 rad = sky_radiance(q.p);
-                    atomicAdd(acc + 0, to_fixed(rad.x));  // ds_add_u64: order-independent integer sum
-                    atomicAdd(acc + 1, to_fixed(rad.y));
-                    atomicAdd(acc + 2, to_fixed(rad.z));
-                    finished = true;
-                } else {
-                    const float4 geo = lds_spheres[hit_slot];
-                    ShadeRec m;
-                    if (SHADE_LDS) {
-                        const float4 m0 = lds_shade[2u * hit_orig], m1 = lds_shade[2u * hit_orig + 1u];
-                        m.albedo[0] = m0.x; m.albedo[1] = m0.y; m.albedo[2] = m0.z; m.param = m0.w;
-                        m.inv_r = m1.x; m.kind = __float_as_uint(m1.y);
-                    } else {
-                        m.albedo[0] = r0.x; m.albedo[1] = r0.y; m.albedo[2] = r0.z; m.param = r0.w;
-                        m.inv_r = r1.x; m.kind = __float_as_uint(r1.y);
-                    }
-                    if (!scatter(mk(geo.x, geo.y, geo.z), m, hit_t, q.p)) {
-                        finished = true;  // absorbed: radiance 0
-                    } else if (++q.depth >= a.max_depth) {
-                        finished = true;  // depth exhausted: radiance 0
-                    }
-                }
-            }
-            // A finished sample bumps its pixel's counter; the lane that completes the pixel
-            // resolves it.  All adds to the entry were issued by earlier LDS instructions of
-            // this wave (or serialised within this one), so the sums it reads are final.
-            bool completed = false;
-            bool line_full = false;  // this lane's pixel was the last of a line buffer
-            if (finished) {
-                q.active = false;
-                unsigned long long* acc = lds_acc + q.entry * kAccWords;
-                // low half: samples done; high half: the segments they took (<= 65535 each, <= 65536 samples)
-                // (A long path counts kLongWeight-fold: what ends a frame is not the work of its last chunks but the LENGTH of
-                // the paths born in them -- fifty bounces at one iteration each -- so chunks in which long paths occur are to go
-                // out first whatever their average; the sum only orders the chunks of the next frame.)
-                const uint32_t segs1 = q.depth < 0xFFFEu ? q.depth + 1u : 0xFFFFu;
-                const uint32_t segs = segs1 > kLongFrom ? (segs1 * kLongWeight < 0xFFFFu ? segs1 * kLongWeight : 0xFFFFu) : segs1;
-                const unsigned long long before = atomicAdd(acc + 3, 1ull | (static_cast<unsigned long long>(segs) << 32));
-                if (static_cast<uint32_t>(before) + 1u == a.spp) {
-                    completed = true;
-                    const uint32_t colour = close_pixel(a, q.pix, acc[0], acc[1], acc[2]);
-                    const uint32_t line = q.line;
-                    if (line == 0u) {
-                        const uint32_t lr = q.pix / a.width, i = q.pix - lr * a.width;
-                        a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = colour;
-                    } else {  // a pixel of a chunk this wave renders alone: into the line buffer
-                        lds_line[(line - 1u) * kChunkPix + q.pix % kChunkPix] = colour;
-                        uint32_t* meta = lds_line_meta + kLineMetaWords * (line - 1u);
-                        atomicAdd(reinterpret_cast<unsigned long long*>(meta + 2), (before >> 32) + segs);  // the chunk's cost, in LDS
-                        const uint32_t done = atomicAdd(meta, 1u);
-                        line_full = done + 1u == meta[1];
-                    }
-                    // what this pixel cost, for the next frame's chunk order (a global atomic leaves the L2 as a 64-byte
-                    // memory-side request: whole chunks sum theirs in LDS and report once, with the line)
-                    // ... and of the pixels handed out one by one, every fourth speaks for its neighbours -- unless a long
-                    // path ended in this one: those are what the order is for, and too rare to be sampled
-                    if (a.chunk_cost != nullptr && line == 0u) {
-                        const unsigned long long cost = (before >> 32) + segs;
-                        if (cost >= static_cast<unsigned long long>(a.spp) * kLongFrom + kLongFrom * kLongWeight)  // (one long path at least)
-                            atomicAdd(a.chunk_cost + q.pix / kChunkPix, cost);
-                        else if ((q.pix & 3u) == 0u)
-                            atomicAdd(a.chunk_cost + q.pix / kChunkPix, 4ull * cost);
-                    }
-                }
-            }
-            // Completed pixels (0-2 per iteration): their accumulator entries return to the wave; a pixel that filled
-            // its line buffer has the line stored -- up to 32 consecutive pixels, 128 bytes, the whole line of the
-            // frame in one store.  (A wave's LDS operations are performed in order: the colour written above is there.)
-            unsigned long long done_mask = __ballot(completed);
-            while (done_mask != 0ull) {
-                const int l = __builtin_ctzll(done_mask);
-                done_mask &= done_mask - 1ull;
-                const uint32_t e = __builtin_amdgcn_readlane(q.entry, l);
-                if (!EXPRESS || e / kAccEntries == wave_in_group) {
-                    free_entries |= 1ull << (e % kAccEntries);
-                } else if (lane == 0u) {  // (the express wave finished another wave's pixel: the entry goes back to its owner)
-                    atomicOr(&xq_returned[e / kAccEntries], 1ull << (e % kAccEntries));
-                }
-                if (__builtin_amdgcn_readlane(static_cast<uint32_t>(line_full), l) != 0u) {
-                    const uint32_t line = __builtin_amdgcn_readlane(q.line, l) - 1u;
-                    const uint32_t first = __builtin_amdgcn_readlane(q.pix, l) / kChunkPix * kChunkPix;
-                    const uint32_t count = g.total_pix - first < kChunkPix ? g.total_pix - first : kChunkPix;
-                    if (lane < count) {
-                        const uint32_t pix = first + lane;
-                        const uint32_t lr = pix / a.width, i = pix - lr * a.width;  // (a chunk may run over the end of a row)
-                        a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = lds_line[line * kChunkPix + lane];
-                    }
-                    if (a.chunk_cost != nullptr && lane == 0u)  // this wave rendered the whole chunk: a plain store
-                        a.chunk_cost[first / kChunkPix] = *reinterpret_cast<const unsigned long long*>(lds_line_meta + kLineMetaWords * line + 2u);
-                    free_lines |= 1u << line;
-                }
-            }
-        };
         bool any_active = false;
         if constexpr (EXPRESS) {
-            if (XDBG_BACK && g.express_ticks != 0u) {  // entries of this wave's pixels that were completed by the express wave
+            if (g.express != 0u) {  // entries of this wave's pixels that were completed by the express wave
                 unsigned long long back = 0ull;
                 if (lane == 0u) back = atomicExch(&xq_returned[wave_in_group], 0ull);
                 free_entries |= static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(back))) |
@@ -2213,55 +2195,6 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     left -= granted;
                 }
             }
-            if constexpr (EXPRESS) {
-                if (XDBG_INTAKE && x_mode) {
-                    uint32_t* ring_words = reinterpret_cast<uint32_t*>(xq_ring);
-                    const uint32_t cap = g.pass_keep;  // (a power of two: launch_path)
-                    if (!x_open && pass_n == 0u) {
-                        // its own records are through: they become the ring.  Flags first, then the credits and the
-                        // go-ahead (a wave's LDS operations are performed in order)
-                        if (lane < cap) ring_words[12u * lane + 11u] = 0u;
-                        if (lane == 0u) {
-                            __hip_atomic_store(&xq_free, cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_store(&xq_on, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                        x_open = true;
-                    }
-                    if (x_open) {
-                        // intake: never more than kSparseParMax paths in all, so that the wave stays in the sparse trace
-                        const unsigned long long act0 = __ballot(sl[0].active);
-                        const uint32_t live = static_cast<uint32_t>(__popcll(act0)) + static_cast<uint32_t>(__popcll(__ballot(sl[1].active)));
-                        const uint32_t room = live < kSparseParMax ? kSparseParMax - live : 0u;
-                        const bool valid = lane < room && __hip_atomic_load(ring_words + 12u * ((x_head + lane) & (cap - 1u)) + 11u,
-                                                                            __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
-                        const unsigned long long vm = __ballot(valid);
-                        const uint32_t n_take = static_cast<uint32_t>(__builtin_ctzll(~vm));  // the valid records from the head on
-                        if (n_take != 0u) {
-                            const uint32_t k = lane_rank(~act0);
-                            if (!sl[0].active && k < n_take) {
-                                Slot& q = sl[0];
-                                const uint32_t at = (x_head + k) & (cap - 1u);
-                                const float4* rec = xq_ring + 3u * at;
-                                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-                                ring_words[12u * at + 11u] = 0u;
-                                q.p.o = mk(r0.x, r0.y, r0.z);
-                                q.p.du = mk(r0.w, r1.x, r1.y);
-                                q.p.att = mk(r1.z, r1.w, r2.x);
-                                q.p.rng = Pcg(__float_as_uint(r2.y));
-                                q.pix = __float_as_uint(r2.z);
-                                const uint32_t packed = __float_as_uint(r2.w);
-                                q.entry = packed & 0x3FFu;
-                                q.line = 0u;
-                                q.depth = packed >> 16;
-                                q.active = true;
-                            }
-                            x_head += n_take;
-                            // (release: the records have been read and their flags cleared before the credits return)
-                            if (lane == 0u) __hip_atomic_fetch_add(&xq_free, n_take, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                    }
-                }
-            }
             any_active = sl[0].active || sl[1].active;
         } else {
             const unsigned long long idle0 = __ballot(!sl[0].active), idle1 = __ballot(!sl[1].active);
@@ -2297,17 +2230,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         // used up and the global queue drained (an entry shortage needs live paths to exist).
         if (__ballot(any_active) == 0ull) {
             if constexpr (EXPRESS) {
-                if (x_mode) {
-                    // The express wave leaves last: until then the others may hand it paths.  (Their records are in LDS
-                    // before their departure tick: once all have left, one look at the head of the ring settles it.)
-                    const bool alone = __hip_atomic_load(&wg_left, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u == waves_in_group;
-                    const bool waiting = x_open && __hip_atomic_load(reinterpret_cast<uint32_t*>(xq_ring) + 12u * (x_head & (g.pass_keep - 1u)) + 11u,
-                                                                     __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
-                    if (alone && !waiting) break;
-                    if (!waiting) __builtin_amdgcn_s_sleep(16);
-                    continue;
-                }
-                if (g.express_ticks != 0u && entry_starved) {  // all its pixels wait for paths that are with the express wave
+                if (g.express != 0u && entry_starved) {  // all its pixels wait for paths that are with the express wave
                     __builtin_amdgcn_s_sleep(16);
                     continue;
                 }
@@ -2330,6 +2253,13 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         if (dbg_dry_seen) ++dbg_tail_iters;
         const unsigned long long dbg_tr0 = wall_clock64();
 #endif
+        if constexpr (kSparseLoop) {
+            if (exhausted && pass_n == 0u && live_paths <= kSparseParMax) {  // nothing left to draw: the rest of the frame in the sparse loop
+                compact_to_slot0(sl, reinterpret_cast<uint32_t*>(lds_results));
+                to_sparse_loop = true;
+                break;
+            }
+        }
         if (ACCEL && live_paths <= kSparseMaxAccel) {
             // few paths left: gather them in slot 0 (the shade and refill code below then runs once, not
             // once per slot), then trace them together
@@ -2386,7 +2316,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         for (int r = 0; r < kSlots; ++r) shade_one(sl[r], best[r], best_i[r], best_o[r], rec0[r], rec1[r]);
         if constexpr (EXPRESS) {
             // Long paths change lanes (see "The express lane"): from a wave that runs the lock-step trace, to the express wave.
-            if (XDBG_PUSH && g.express_ticks != 0u && !x_wave && live_paths > kSparseMaxAccel) {
+            if (g.express != 0u && live_paths > kSparseMaxAccel) {
                 bool w[kSlots];
                 unsigned long long m[kSlots];
 #pragma unroll
@@ -2394,7 +2324,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     w[r] = sl[r].active && sl[r].depth >= g.express_from && sl[r].line == 0u;
                     m[r] = __ballot(w[r]);
                 }
-                if ((m[0] | m[1]) != 0ull && __hip_atomic_load(&xq_on, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {
+                if ((m[0] | m[1]) != 0ull) {
                     constexpr uint32_t kPushMax = 16;  // records one wave asks for at a time
                     const uint32_t c0 = static_cast<uint32_t>(__popcll(m[0]));
                     const uint32_t all = c0 + static_cast<uint32_t>(__popcll(m[1]));
@@ -2437,6 +2367,79 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             dbg_tail_cyc[2] += DBG_STAMP() - t2;
         }
 #endif
+    }
+
+    // ---- the sparse loop: the express wave's whole frame, and the end of every other wave's (EXPRESS) ----
+    // All paths sit in slot 0, at most kSparseParMax of them; an iteration is the path-parallel trace and one pass of the
+    // shade code.  The express wave first takes what the ring holds (the valid records from its head on).
+    if constexpr (kSparseLoop) {
+        if (to_sparse_loop) {
+#ifdef RTIOW_EXPRESS_PRIO
+            if (x_wave) __builtin_amdgcn_s_setprio(RTIOW_EXPRESS_PRIO);  // (its iterations are what long paths wait for)
+#endif
+            uint32_t x_head = 0u;
+            uint32_t* ring_words = reinterpret_cast<uint32_t*>(xq_ring);
+            const uint32_t cap = g.pass_keep;  // (a power of two: launch_path)
+            for (;;) {
+                const unsigned long long act0 = __ballot(sl[0].active);
+                uint32_t live = static_cast<uint32_t>(__popcll(act0));
+                if (x_wave) {
+                    const uint32_t room = kSparseParMax - live;
+                    const bool valid = lane < room && __hip_atomic_load(ring_words + 12u * ((x_head + lane) & (cap - 1u)) + 11u,
+                                                                        __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
+                    const unsigned long long vm = __ballot(valid);
+                    const uint32_t n_take = static_cast<uint32_t>(__builtin_ctzll(~vm));  // (room <= 32: never all 64 bits)
+                    if (n_take != 0u) {
+                        const uint32_t k = lane_rank(~act0);
+                        if (!sl[0].active && k < n_take) {
+                            Slot& q = sl[0];
+                            const uint32_t at = (x_head + k) & (cap - 1u);
+                            const float4* rec = xq_ring + 3u * at;
+                            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                            ring_words[12u * at + 11u] = 0u;
+                            q.p.o = mk(r0.x, r0.y, r0.z);
+                            q.p.du = mk(r0.w, r1.x, r1.y);
+                            q.p.att = mk(r1.z, r1.w, r2.x);
+                            q.p.rng = Pcg(__float_as_uint(r2.y));
+                            q.pix = __float_as_uint(r2.z);
+                            const uint32_t packed = __float_as_uint(r2.w);
+                            q.entry = packed & 0x3FFu;
+                            q.line = 0u;
+                            q.depth = packed >> 16;
+                            q.active = true;
+                        }
+                        x_head += n_take;
+                        live += n_take;
+                        // (release: the records have been read and their flags cleared before the credits return)
+                        if (lane == 0u) __hip_atomic_fetch_add(&xq_free, n_take, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                if (live == 0u) {
+                    if (!x_wave) break;
+                    // The express wave leaves last: until then the others may hand it paths.  (Their records are in LDS
+                    // before their departure tick: once all have left, one look at the head of the ring settles it.)
+                    const bool alone = __hip_atomic_load(&wg_left, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u == waves_in_group;
+                    const bool waiting = __hip_atomic_load(ring_words + 12u * (x_head & (cap - 1u)) + 11u, __ATOMIC_ACQUIRE,
+                                                           __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
+                    if (alone && !waiting) break;
+                    if (!waiting) __builtin_amdgcn_s_sleep(8);
+                    continue;
+                }
+#ifdef RTIOW_DEBUG_TIMELINE
+                if (tl_dry != 0ull) ++tl_tail_iters;
+                TL_MARK(tl_sparse);
+                ++tl_sparse_iters;
+                tl_sparse_paths += live;
+#endif
+                float best[kSlots];
+                int best_i[kSlots];
+                uint32_t best_o[kSlots];
+                trace_sparse_parallel<kSlots, false>(lds_spheres, lds_cidx, lds_cbounds, a, lds_items, lds_results, sl, best, best_i,
+                                                     best_o, n_tests);
+                const float4 none = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                shade_one(sl[0], best[0], best_i[0], best_o[0], none, none);
+            }
+        }
     }
 
 #ifdef RTIOW_DEBUG_TIMELINE
@@ -2796,10 +2799,12 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     uint32_t threads = 0u;
     int per_cu = 0;
     size_t lds = 0u;
-    const uint32_t pinned = getenv("RTIOW_DEBUG_THREADS") ? strtoul(getenv("RTIOW_DEBUG_THREADS"), nullptr, 10) : 0u;
+    // (the express variant: ONE group of twelve waves per CU, the twelfth being its express wave)
+    const uint32_t pinned = express ? static_cast<uint32_t>(kAccelMaxThreads)
+                                    : (getenv("RTIOW_DEBUG_THREADS") ? strtoul(getenv("RTIOW_DEBUG_THREADS"), nullptr, 10) : 0u);
     // (the small-scene variant of the clustered kernel is compiled for groups of at most 512: with the bound at
     // 768 the same source came out 3 % slower on the cover frame)
-    const uint32_t t_max = accel ? (shade_lds ? static_cast<uint32_t>(RTIOW_SMALL_MAX_THREADS) : static_cast<uint32_t>(kAccelMaxThreads)) : 1024u;
+    const uint32_t t_max = accel ? (shade_lds && !express ? static_cast<uint32_t>(RTIOW_SMALL_MAX_THREADS) : static_cast<uint32_t>(kAccelMaxThreads)) : 1024u;
     uint32_t keep_env = kPassKeep;
     if (const char* v = getenv("RTIOW_DEBUG_PASS_KEEP")) keep_env = strtoul(v, nullptr, 10) ? kPassKeep : 0u;  // tuning only
     for (int pass = 0; pass < 2; ++pass) {  // with the records first; without them only if that keeps more waves on a CU
@@ -2834,10 +2839,9 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     if (threads == 0u) return hipErrorInvalidValue;  // rtSetScene's sphere limit keeps this from happening
     // The ring of the express lane is the express wave's own block of pass_keep records (a power of two of them); a
     // workgroup needs a second wave to hand anything over, and entry numbers must fit the record's ten bits.
-    if (express && g.pass_keep >= 16u && (g.pass_keep & (g.pass_keep - 1u)) == 0u && threads >= 128u && threads <= 1024u) {
-        uint32_t us = 450u;
-        if (const char* v = getenv("RTIOW_DEBUG_EXPRESS_US")) us = strtoul(v, nullptr, 10);  // tuning only
-        g.express_ticks = us * 100u;  // wall_clock64 ticks at 100 MHz
+    // (RTIOW_DEBUG_EXPRESS=2: the express variant's kernel and group size with no express wave -- what the variant itself costs)
+    if (express && atoi(getenv("RTIOW_DEBUG_EXPRESS")) != 2 && g.pass_keep >= 16u && (g.pass_keep & (g.pass_keep - 1u)) == 0u && threads >= 128u) {  // (the ring: a power of two of records)
+        g.express = 1u;
         g.express_from = kLongFrom;
         if (const char* v = getenv("RTIOW_DEBUG_EXPRESS_FROM")) g.express_from = strtoul(v, nullptr, 10);  // tuning only
         if (g.express_from < 1u) g.express_from = 1u;
