@@ -488,7 +488,6 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 #define RTIOW_POOL_WORK 40000u
 #endif
 constexpr uint32_t kPoolWork = RTIOW_POOL_WORK;
-
 #ifndef RTIOW_LONG_FROM
 #define RTIOW_LONG_FROM 12
 #endif
@@ -540,13 +539,9 @@ struct PersistArgs {
     float lens_rho;        // bound of the lens offset |off|, with its margin
     float h_len, v_len;    // |cam.horizontal|, |cam.vertical|, with their margin
     float abs_margin;      // absolute slack of the cone test: 2^-16 of the scene's coordinate range
-    // the express lane of the small-scene clustered kernel (see "The express lane" below)
-    uint32_t express;        // != 0: the last wave of every workgroup is its express wave
-    uint32_t express_from;   // segments a path must have taken to be handed over
 };
 using PersistentKernelFn = void (*)(PathArgs, PersistArgs);
-// path_persistent_kernel<true, true, false>, from the second compilation of this file
-PersistentKernelFn small_clustered_kernel();
+PersistentKernelFn small_clustered_kernel();  // path_persistent_kernel<true, true>, from the second compilation of this file
 namespace {
 
 DI void examine_candidate(const float4* lds, uint32_t j, uint32_t n, const Path& p, float& best,
@@ -1637,51 +1632,34 @@ constexpr int kAccelMaxThreads = RTIOW_ACCEL_MAX_THREADS;
 // is held there by amdgpu_waves_per_eu, which its 768-thread groups need.  The small-scene variant gets there by itself
 // (tests/test_host_logic.py checks the compiler's report) and is left alone: with the attribute the same source
 // schedules differently and the cover frame takes 4 % longer, 9.82 -> 10.25 ms.)
-// ---- The express lane (EXPRESS; small-scene clustered kernel, small frames) -----------------------------------------
-// A path advances one bounce per iteration of its wave, and an iteration of a full wave takes ~17 us whatever the
-// path: the 0.09 % of paths that bounce fifty times inside a glass ball live 0.85 ms.  On a small frame (one eighth of
-// the cover frame: 1.1 ms of work) every such path born after the first quarter of the frame is still alive when the
-// queues run dry, and the frame ends with every wave nursing two or three of them (tools/timeline.py) -- a fixed cost
-// of ~0.3 ms per frame that no amount of late work explains, and the reason eight tiles did not take an eighth of
-// the time.  So long paths change lanes.  The EXPRESS variant runs ONE workgroup of twelve waves per CU; its last
-// wave draws no pixels at all: it takes the paths the other eleven hand it -- every path of express_from segments or
-// more (2.5 % of all segments lie beyond the twelfth: tools/path_lengths.py) -- through a ring of records in LDS (the
-// wave's own primary-pass records, which it never uses).  It holds at most kSparseParMax of them, runs the path-parallel
-// sparse trace on them and nothing else (~5 us per bounce), so a fifty-bounce path lives 0.2 + 0.2 ms.
-// Which wave traces a path is immaterial to the frame: the pixel's accumulator entry (workgroup LDS, integer sums)
-// is addressed by number, whoever adds the last sample resolves and stores the pixel, and the entry goes back to the
-// wave that owns it through a mask in LDS (xq_returned).  Only pixels that go straight to the frame change lanes
-// (line == 0; a pixel of a line buffer stays with the wave that assembles the line -- small frames have none).
-// Ring protocol: xq_free counts the free records (producers take credits with one atomic, give them back if there are
-// too few), xq_tail numbers the places; a record's last word (never 0 when valid) is written after the rest and
-// cleared by the consumer, which takes the valid records from its head on and returns their credits.
-// The same loop -- sparse trace, shade, nothing else -- is where every other wave ends its frame once the queues are
-// dry and it is down to kSparseParMax paths (no refill attempts, no second slot, no compaction per iteration).
-template <bool SHADE_LDS, bool ACCEL, bool EXPRESS = false>
-__global__ __launch_bounds__(ACCEL ? (SHADE_LDS && !EXPRESS ? RTIOW_SMALL_MAX_THREADS : kAccelMaxThreads) : 1024) __attribute__((amdgpu_waves_per_eu((ACCEL && !SHADE_LDS) || EXPRESS ? 3 : 1)))
-void path_persistent_kernel(PathArgs a, PersistArgs g) {
-    static_assert(!EXPRESS || (SHADE_LDS && ACCEL), "the express lane lives in the small-scene clustered kernel");
+// ---- The sparse loop at the end of a wave's frame (small-scene clustered kernel) -----------------------------------------------
+// Once the queues are dry and a wave is down to kSparseParMax paths, nothing of the main loop's refill is of use to it
+// any more -- no pool to fetch, no primary pass, no second slot: it gathers its paths in slot 0 once and ends its frame
+// in a loop of its own, path-parallel sparse trace + one pass of the shade code.  What ends a small frame is the latency
+// of ~50 such iterations (the fifty-bounce paths inside glass: 0.09 % of all paths, tools/path_lengths.py), so every
+// instruction off them counts: 1/8 of the cover frame 1.45 -> 1.40 ms, a 1-spp frame 0.51 -> 0.48, the whole frame
+// unchanged (8.21 / 8.27, within noise).
+// (Round 3 also built the "express lane" VERDICT r2 proposed -- paths of 12+ segments handed, through a ring of LDS
+// records, to a dedicated wave per workgroup that runs nothing but the sparse trace; frames identical, but the variant
+// lost: profiles/r03_express_lane_ablation.txt; the code is in commit "Express lane v2".)
 #ifndef RTIOW_TAIL_LOOP
-#define RTIOW_TAIL_LOOP 0
+#define RTIOW_TAIL_LOOP 1  // (-DRTIOW_TAIL_LOOP=0: A/B only)
 #endif
-    // the sparse loop at the end of a wave's frame (see "The express lane"): the express variant, or -DRTIOW_TAIL_LOOP=1
-    constexpr bool kSparseLoop = EXPRESS || (RTIOW_TAIL_LOOP != 0 && SHADE_LDS && ACCEL);
+template <bool SHADE_LDS, bool ACCEL>
+__global__ __launch_bounds__(ACCEL ? (SHADE_LDS ? RTIOW_SMALL_MAX_THREADS : kAccelMaxThreads) : 1024) __attribute__((amdgpu_waves_per_eu(ACCEL && !SHADE_LDS ? 3 : 1)))
+void path_persistent_kernel(PathArgs a, PersistArgs g) {
     // LDS: sphere list [g.n_pad float4] — the flat list, or (ACCEL) the clustered list's slots, then
     // (ACCEL) the slots' original indices [g.n_pad u32] and the boxes [2 (a.n_clusters + a.n_super) float4];
     // then (SHADE_LDS) two float4 of shading record per sphere; then the accumulator entries of every
     // wave of the workgroup (a wave allocates only from its own 64).
+    // (small scenes only: the large-scene variant, at its 168 registers, spills two of them with the second copy of the
+    // sparse trace, and the end of its frames -- seconds long -- does not matter)
+    constexpr bool kSparseLoop = RTIOW_TAIL_LOOP != 0 && ACCEL && SHADE_LDS;
     extern __shared__ float4 lds_spheres[];
     __shared__ unsigned long long wg_sums[3];  // paths, segments, tests of the waves that have left
     __shared__ unsigned int wg_left;           // how many have
-    [[maybe_unused]] __shared__ unsigned long long xq_returned[16];  // (EXPRESS) per wave: accumulator entries the express wave gives back
-    [[maybe_unused]] __shared__ unsigned int xq_tail, xq_free;  // (EXPRESS) ring: next place, free records
     if (threadIdx.x < 3u) wg_sums[threadIdx.x] = 0ull;
     if (threadIdx.x == 3u) wg_left = 0u;
-    if (EXPRESS) {
-        if (threadIdx.x < 16u) xq_returned[threadIdx.x] = 0ull;
-        if (threadIdx.x == 16u) xq_tail = 0u;
-        if (threadIdx.x == 17u) xq_free = g.express != 0u ? g.pass_keep : 0u;  // (every record of the ring is free)
-    }
     uint32_t* lds_cidx = reinterpret_cast<uint32_t*>(lds_spheres + g.n_pad);
     float4* lds_cbounds = reinterpret_cast<float4*>(lds_cidx + (ACCEL ? g.n_pad : 0u));
     float4* lds_shade = lds_cbounds + (ACCEL ? 2u * (a.n_clusters + a.n_super) : 0u);
@@ -1714,12 +1692,6 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         const float4* src = reinterpret_cast<const float4*>(a.shade);
         for (uint32_t i = threadIdx.x; i < 2u * a.n; i += blockDim.x) lds_shade[i] = src[i];
     }
-    if (EXPRESS && g.express != 0u && threadIdx.x < g.pass_keep) {  // the ring: the last wave's records, all invalid
-        uint32_t* ring_words = reinterpret_cast<uint32_t*>(
-            reinterpret_cast<unsigned char*>(lds_acc + waves_in_group * (kWaveAccBytes / 8u)) +
-            waves_in_group * (kWaveLineBytes + wave_item_bytes(a.n_super != 0u)) + (waves_in_group - 1u) * g.pass_keep * kPassRecBytes);
-        ring_words[12u * threadIdx.x + 11u] = 0u;
-    }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
 
@@ -1746,12 +1718,6 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     uint32_t cur_line = 0u;                  // line buffer of the chunk being handed out, + 1 (0: its pixels go straight to the frame)
     [[maybe_unused]] uint32_t pass_n = 0u;   // (clustered) camera paths waiting in the wave's LDS records for an idle slot
     [[maybe_unused]] bool exhausted = false; // the global queue has been drained
-    // (EXPRESS) the ring is the express wave's own primary-pass records; every wave knows where they are
-    [[maybe_unused]] float4* xq_ring = reinterpret_cast<float4*>(
-        reinterpret_cast<unsigned char*>(lds_acc + waves_in_group * (kWaveAccBytes / 8u)) +
-        waves_in_group * (kWaveLineBytes + wave_item_bytes(a.n_super != 0u)) + (waves_in_group - 1u) * g.pass_keep * kPassRecBytes);
-    [[maybe_unused]] const bool x_wave = EXPRESS && g.express != 0u && wave_in_group == waves_in_group - 1u;
-    [[maybe_unused]] bool entry_starved = false;  // the last hand_out stopped for want of an accumulator entry
 #ifdef RTIOW_DEBUG_TIMELINE
     const unsigned long long tl_start = wall_clock64();
     if (lane == 0u) atomicMax(&a.counters->not_t0, ~tl_start);
@@ -1856,11 +1822,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             const int l = __builtin_ctzll(done_mask);
             done_mask &= done_mask - 1ull;
             const uint32_t e = __builtin_amdgcn_readlane(q.entry, l);
-            if (!EXPRESS || e / kAccEntries == wave_in_group) {
-                free_entries |= 1ull << (e % kAccEntries);
-            } else if (lane == 0u) {  // (the express wave finished another wave's pixel: the entry goes back to its owner)
-                atomicOr(&xq_returned[e / kAccEntries], 1ull << (e % kAccEntries));
-            }
+            free_entries |= 1ull << (e % kAccEntries);
             if (__builtin_amdgcn_readlane(static_cast<uint32_t>(line_full), l) != 0u) {
                 const uint32_t line = __builtin_amdgcn_readlane(q.line, l) - 1u;
                 const uint32_t first = __builtin_amdgcn_readlane(q.pix, l) / kChunkPix * kChunkPix;
@@ -1876,10 +1838,8 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             }
         }
     };
-    // (EXPRESS) the express wave never enters the main loop; the others leave it for the sparse loop below once their
-    // queues are dry and they are down to kSparseParMax paths
-    [[maybe_unused]] bool to_sparse_loop = x_wave;
-    for (; !x_wave;) {
+    [[maybe_unused]] bool to_sparse_loop = false;  // the wave leaves the main loop for the sparse loop below
+    for (;;) {
         [[maybe_unused]] const unsigned long long t0 = DBG_STAMP();
         // ---- refill ---------------------------------------------------------
         // Hands out the next `want` samples of the wave's pool, pixel by pixel: on_range(first, n, pixel, entry, sample)
@@ -1888,7 +1848,6 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         // (fewer than `want` once the queues are dry or the accumulator entries are all in use).
         auto hand_out = [&](uint32_t want, auto&& on_range) -> uint32_t {
             uint32_t served = 0u;  // wave-uniform
-            entry_starved = false;
             while (served < want) {  // one trip per pixel touched (1-2 unless spp is tiny)
                 if (cur_s == a.spp) {  // open the next pixel of the pool
                     if (pool_next == pool_end) {
@@ -1994,10 +1953,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                         ++pool_next;
                         continue;
                     }
-                    if (free_entries == 0ull) {  // 64 pixels in flight: wait for one to finish
-                        entry_starved = true;
-                        break;
-                    }
+                    if (free_entries == 0ull) break;  // 64 pixels in flight: wait for one to finish
                     cur_entry = static_cast<uint32_t>(__builtin_ctzll(free_entries));
                     free_entries &= free_entries - 1ull;
                     cur_pix = pix;
@@ -2013,14 +1969,6 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             return served;
         };
         bool any_active = false;
-        if constexpr (EXPRESS) {
-            if (g.express != 0u) {  // entries of this wave's pixels that were completed by the express wave
-                unsigned long long back = 0ull;
-                if (lane == 0u) back = atomicExch(&xq_returned[wave_in_group], 0ull);
-                free_entries |= static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(back))) |
-                                (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(back >> 32))) << 32);
-            }
-        }
         if constexpr (ACCEL) {
             // Idle slots are filled with camera paths that have already taken their first segment: the primary pass
             // makes up to 64 camera rays at a time (one per lane, consecutive samples of the pool's pixels), traces them
@@ -2228,15 +2176,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         }
         // No live path anywhere in the wave: every slot asked and got nothing, so the pool is
         // used up and the global queue drained (an entry shortage needs live paths to exist).
-        if (__ballot(any_active) == 0ull) {
-            if constexpr (EXPRESS) {
-                if (g.express != 0u && entry_starved) {  // all its pixels wait for paths that are with the express wave
-                    __builtin_amdgcn_s_sleep(16);
-                    continue;
-                }
-            }
-            break;
-        }
+        if (__ballot(any_active) == 0ull) break;
 #ifdef RTIOW_DEBUG_TIMELINE
         if (tl_dry != 0ull) ++tl_tail_iters;
 #endif
@@ -2314,49 +2254,6 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         }
 #pragma unroll
         for (int r = 0; r < kSlots; ++r) shade_one(sl[r], best[r], best_i[r], best_o[r], rec0[r], rec1[r]);
-        if constexpr (EXPRESS) {
-            // Long paths change lanes (see "The express lane"): from a wave that runs the lock-step trace, to the express wave.
-            if (g.express != 0u && live_paths > kSparseMaxAccel) {
-                bool w[kSlots];
-                unsigned long long m[kSlots];
-#pragma unroll
-                for (int r = 0; r < kSlots; ++r) {
-                    w[r] = sl[r].active && sl[r].depth >= g.express_from && sl[r].line == 0u;
-                    m[r] = __ballot(w[r]);
-                }
-                if ((m[0] | m[1]) != 0ull) {
-                    constexpr uint32_t kPushMax = 16;  // records one wave asks for at a time
-                    const uint32_t c0 = static_cast<uint32_t>(__popcll(m[0]));
-                    const uint32_t all = c0 + static_cast<uint32_t>(__popcll(m[1]));
-                    const uint32_t cnt = all < kPushMax ? all : kPushMax;
-                    uint32_t base = ~0u;
-                    if (lane == 0u) {  // credits first (given back if there are too few), then the places
-                        const uint32_t had = atomicSub(&xq_free, cnt);
-                        if (static_cast<int32_t>(had) >= static_cast<int32_t>(cnt)) base = atomicAdd(&xq_tail, cnt);
-                        else atomicAdd(&xq_free, cnt);
-                    }
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base != ~0u) {
-#pragma unroll
-                        for (int r = 0; r < kSlots; ++r) {
-                            const uint32_t k = (r == 0 ? 0u : c0) + lane_rank(m[r]);
-                            if (w[r] && k < cnt) {
-                                Slot& q = sl[r];
-                                const uint32_t at = (base + k) & (g.pass_keep - 1u);
-                                float4* rec = xq_ring + 3u * at;
-                                rec[0] = make_float4(q.p.o.x, q.p.o.y, q.p.o.z, q.p.du.x);
-                                rec[1] = make_float4(q.p.du.y, q.p.du.z, q.p.att.x, q.p.att.y);
-                                rec[2] = make_float4(q.p.att.z, __uint_as_float(q.p.rng.state), __uint_as_float(q.pix), 0.0f);
-                                // the word that makes the record valid, after the rest (entry < 1024, depth < 65536: launch_path)
-                                __hip_atomic_store(reinterpret_cast<uint32_t*>(xq_ring) + 12u * at + 11u, q.entry | (q.depth << 16),
-                                                   __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                q.active = false;
-                            }
-                        }
-                    }
-                }
-            }
-        }
         DBG_ADD(dbg_t_refill, t1 - t0);
         DBG_ADD(dbg_t_trace, t2 - t1);
         DBG_ADD(dbg_t_shade, DBG_STAMP() - t2);
@@ -2369,62 +2266,14 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
 #endif
     }
 
-    // ---- the sparse loop: the express wave's whole frame, and the end of every other wave's (EXPRESS) ----
+    // ---- the sparse loop: the end of a wave's frame (see above) ----
     // All paths sit in slot 0, at most kSparseParMax of them; an iteration is the path-parallel trace and one pass of the
-    // shade code.  The express wave first takes what the ring holds (the valid records from its head on).
+    // shade code.
     if constexpr (kSparseLoop) {
         if (to_sparse_loop) {
-#ifdef RTIOW_EXPRESS_PRIO
-            if (x_wave) __builtin_amdgcn_s_setprio(RTIOW_EXPRESS_PRIO);  // (its iterations are what long paths wait for)
-#endif
-            uint32_t x_head = 0u;
-            uint32_t* ring_words = reinterpret_cast<uint32_t*>(xq_ring);
-            const uint32_t cap = g.pass_keep;  // (a power of two: launch_path)
             for (;;) {
-                const unsigned long long act0 = __ballot(sl[0].active);
-                uint32_t live = static_cast<uint32_t>(__popcll(act0));
-                if (x_wave) {
-                    const uint32_t room = kSparseParMax - live;
-                    const bool valid = lane < room && __hip_atomic_load(ring_words + 12u * ((x_head + lane) & (cap - 1u)) + 11u,
-                                                                        __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
-                    const unsigned long long vm = __ballot(valid);
-                    const uint32_t n_take = static_cast<uint32_t>(__builtin_ctzll(~vm));  // (room <= 32: never all 64 bits)
-                    if (n_take != 0u) {
-                        const uint32_t k = lane_rank(~act0);
-                        if (!sl[0].active && k < n_take) {
-                            Slot& q = sl[0];
-                            const uint32_t at = (x_head + k) & (cap - 1u);
-                            const float4* rec = xq_ring + 3u * at;
-                            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-                            ring_words[12u * at + 11u] = 0u;
-                            q.p.o = mk(r0.x, r0.y, r0.z);
-                            q.p.du = mk(r0.w, r1.x, r1.y);
-                            q.p.att = mk(r1.z, r1.w, r2.x);
-                            q.p.rng = Pcg(__float_as_uint(r2.y));
-                            q.pix = __float_as_uint(r2.z);
-                            const uint32_t packed = __float_as_uint(r2.w);
-                            q.entry = packed & 0x3FFu;
-                            q.line = 0u;
-                            q.depth = packed >> 16;
-                            q.active = true;
-                        }
-                        x_head += n_take;
-                        live += n_take;
-                        // (release: the records have been read and their flags cleared before the credits return)
-                        if (lane == 0u) __hip_atomic_fetch_add(&xq_free, n_take, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
-                if (live == 0u) {
-                    if (!x_wave) break;
-                    // The express wave leaves last: until then the others may hand it paths.  (Their records are in LDS
-                    // before their departure tick: once all have left, one look at the head of the ring settles it.)
-                    const bool alone = __hip_atomic_load(&wg_left, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u == waves_in_group;
-                    const bool waiting = __hip_atomic_load(ring_words + 12u * (x_head & (cap - 1u)) + 11u, __ATOMIC_ACQUIRE,
-                                                           __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
-                    if (alone && !waiting) break;
-                    if (!waiting) __builtin_amdgcn_s_sleep(8);
-                    continue;
-                }
+                [[maybe_unused]] const uint32_t live = static_cast<uint32_t>(__popcll(__ballot(sl[0].active)));
+                if (live == 0u) break;
 #ifdef RTIOW_DEBUG_TIMELINE
                 if (tl_dry != 0ull) ++tl_tail_iters;
                 TL_MARK(tl_sparse);
@@ -2434,10 +2283,15 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 float best[kSlots];
                 int best_i[kSlots];
                 uint32_t best_o[kSlots];
-                trace_sparse_parallel<kSlots, false>(lds_spheres, lds_cidx, lds_cbounds, a, lds_items, lds_results, sl, best, best_i,
-                                                     best_o, n_tests);
-                const float4 none = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                shade_one(sl[0], best[0], best_i[0], best_o[0], none, none);
+                trace_sparse_parallel<kSlots, !SHADE_LDS>(lds_spheres, lds_cidx, lds_cbounds, a, lds_items, lds_results, sl, best, best_i,
+                                                          best_o, n_tests);
+                float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0;
+                if (!SHADE_LDS && sl[0].active && best_i[0] >= 0) {  // (large scenes: the hit's shading record from L2)
+                    const float4* src = reinterpret_cast<const float4*>(a.shade + best_o[0]);
+                    r0 = src[0];
+                    r1 = src[1];
+                }
+                shade_one(sl[0], best[0], best_i[0], best_o[0], r0, r1);
             }
         }
     }
@@ -2646,7 +2500,7 @@ __global__ __launch_bounds__(1024) void order_chunks_kernel(unsigned long long* 
 // 8.64 -> 8.40 ms, one eighth of it 1.46 -> 1.41 (interleaved A/B, tools/ab_bench.py).  The large-scene variant spills
 // under that scheduler (C5 1.16 -> 1.22 s) and the flat-list kernels lose 1 % to it, so they stay with the default.
 #ifdef RTIOW_TU_SMALL_CLUSTERED
-PersistentKernelFn small_clustered_kernel() { return path_persistent_kernel<true, true, false>; }
+PersistentKernelFn small_clustered_kernel() { return path_persistent_kernel<true, true>; }
 #else
 
 hipError_t launch_order_chunks(unsigned long long* cost, uint32_t* order, uint32_t n_chunks, uint32_t spp, hipStream_t stream) {
@@ -2744,7 +2598,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // default: the clustered list from kClusteredFrom spheres on (cover scene: 2.1x faster than the
     // flat list; frames are byte-identical either way), the flat list for the handful-of-spheres scenes
     bool accel = kernel == KERNEL_CLUSTERED || kernel == KERNEL_CLUSTERED_PASS || (kernel == KERNEL_DEFAULT && a.n >= kClusteredFrom);
-    constexpr size_t kLdsPerCu = 160u * 1024u - 256u;  // (the kernel's static __shared__ words -- up to 176 bytes -- come on top of the dynamic part)
+    constexpr size_t kLdsPerCu = 160u * 1024u - 256u;  // (the kernel's static __shared__ words come on top of the dynamic part)
     // The clustered list must fit the LDS beside four waves' buffers.  The very largest scenes give up
     // the super-cluster level first (its boxes and second work list), then fall back to the flat list.
     auto clustered_fits = [&](uint32_t n_super) {
@@ -2782,13 +2636,8 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // large scene with no room for them (C5: one 768-thread group beside 92 KB of list) does without -- its passes then
     // make no more paths than there are idle slots, and the records sit in the two-level work-list area alone
     auto wave_bytes = [&](uint32_t keep) { return kWaveAccBytes + kWaveLineBytes + (accel ? item_bytes + keep * kPassRecBytes : 0u); };
-    // the express lane (long paths handed to the last wave of each workgroup near the end of a frame): the small-scene
-    // clustered kernel; RTIOW_DEBUG_EXPRESS=0 runs the variant compiled without it (tuning / A-B only)
-    const bool express = accel && shade_lds && a.max_depth <= 0xFFFFu && getenv("RTIOW_DEBUG_EXPRESS") && atoi(getenv("RTIOW_DEBUG_EXPRESS")) != 0;
     void (*kernel_fn)(PathArgs, PersistArgs) =
-        // (the express variant sits at the 168-register edge: it keeps to it under the default scheduler, held there by
-        // amdgpu_waves_per_eu, and spills 33 registers under iterative-ilp -- so it is compiled here, not in the second pass)
-        accel ? (shade_lds ? (express ? path_persistent_kernel<true, true, true> : small_clustered_kernel()) : path_persistent_kernel<false, true>)
+        accel ? (shade_lds ? small_clustered_kernel() : path_persistent_kernel<false, true>)
               : (shade_lds ? path_persistent_kernel<true, false> : path_persistent_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsPerCu));
@@ -2799,12 +2648,10 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     uint32_t threads = 0u;
     int per_cu = 0;
     size_t lds = 0u;
-    // (the express variant: ONE group of twelve waves per CU, the twelfth being its express wave)
-    const uint32_t pinned = express ? static_cast<uint32_t>(kAccelMaxThreads)
-                                    : (getenv("RTIOW_DEBUG_THREADS") ? strtoul(getenv("RTIOW_DEBUG_THREADS"), nullptr, 10) : 0u);
+    const uint32_t pinned = getenv("RTIOW_DEBUG_THREADS") ? strtoul(getenv("RTIOW_DEBUG_THREADS"), nullptr, 10) : 0u;
     // (the small-scene variant of the clustered kernel is compiled for groups of at most 512: with the bound at
     // 768 the same source came out 3 % slower on the cover frame)
-    const uint32_t t_max = accel ? (shade_lds && !express ? static_cast<uint32_t>(RTIOW_SMALL_MAX_THREADS) : static_cast<uint32_t>(kAccelMaxThreads)) : 1024u;
+    const uint32_t t_max = accel ? (shade_lds ? static_cast<uint32_t>(RTIOW_SMALL_MAX_THREADS) : static_cast<uint32_t>(kAccelMaxThreads)) : 1024u;
     uint32_t keep_env = kPassKeep;
     if (const char* v = getenv("RTIOW_DEBUG_PASS_KEEP")) keep_env = strtoul(v, nullptr, 10) ? kPassKeep : 0u;  // tuning only
     for (int pass = 0; pass < 2; ++pass) {  // with the records first; without them only if that keeps more waves on a CU
@@ -2837,15 +2684,6 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
         g.primary_all = (cull && !getenv("RTIOW_DEBUG_NO_CONE")) ? 0u : 1u;
     }
     if (threads == 0u) return hipErrorInvalidValue;  // rtSetScene's sphere limit keeps this from happening
-    // The ring of the express lane is the express wave's own block of pass_keep records (a power of two of them); a
-    // workgroup needs a second wave to hand anything over, and entry numbers must fit the record's ten bits.
-    // (RTIOW_DEBUG_EXPRESS=2: the express variant's kernel and group size with no express wave -- what the variant itself costs)
-    if (express && atoi(getenv("RTIOW_DEBUG_EXPRESS")) != 2 && g.pass_keep >= 16u && (g.pass_keep & (g.pass_keep - 1u)) == 0u && threads >= 128u) {  // (the ring: a power of two of records)
-        g.express = 1u;
-        g.express_from = kLongFrom;
-        if (const char* v = getenv("RTIOW_DEBUG_EXPRESS_FROM")) g.express_from = strtoul(v, nullptr, 10);  // tuning only
-        if (g.express_from < 1u) g.express_from = 1u;
-    }
     // persistent grid: fill the chip once; never more slots than samples
     unsigned long long grid = static_cast<unsigned long long>(num_cus > 0 ? num_cus : 256) * per_cu;
     const unsigned long long samples = static_cast<unsigned long long>(g.total_pix) * a.spp;
