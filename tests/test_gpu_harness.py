@@ -67,6 +67,9 @@ def test_harness_json_metrics(tmp_path):
     res = subprocess.run([MAIN, "--scene", "three", "--width", "64", "--height", "36", "--spp", "2", "--frames", "3", "--json", "1",
                           "--out", out], check=True, capture_output=True, text=True)
     lines = [json.loads(x) for x in res.stdout.strip().splitlines()]
+    summary = lines.pop()  # bench.py's fields for this path, after the last frame
+    assert summary["n_gpus"] == 1 and summary["steps"] == 3 and summary["warmup"] == 0 and summary["ms_per_step"] > 0
+    assert summary["config"]["transport"] == "single" and len(summary["config"]["device_kernel_ms"]) == 1
     assert [x["frame"] for x in lines] == [0, 1, 2]
     for x in lines:
         assert x["width"] == 64 and x["height"] == 36 and x["spp"] == 2 and x["spheres"] == 5 and x["gpus"] == 1

@@ -104,6 +104,29 @@ def test_harness_gpus_flag(oracle, tmp_path):
         assert np.array_equal(img, want[::-1, :, :3])
 
 
+def test_harness_multi_gpu_bench_line(tmp_path):
+    """`rtiow_main --gpus N --json 1` ends with bench.py's fields for the C-ABI path (rtMultiRender) --
+    rehearsed here as four tiles on device 0 (peer-copy transport): ms per frame with one frame in flight, every device's
+    tile kernel time, the transport by its real name, the gathered frame equal to the one device 0 renders alone, and its
+    CRC-32 equal to the ORACLE's for the same workload (tests/golden/frame_golden.json: cover_300x200_10spp)."""
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "frame_golden.json")))["cover_300x200_10spp"]
+    res = subprocess.run([MAIN, "--scene", "cover", "--width", "300", "--height", "200", "--spp", "10", "--devices", "0,0,0,0",
+                          "--frames", "5", "--warmup", "2", "--json", "1", "--out", str(tmp_path / "b.ppm")],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-1500:])
+    lines = [json.loads(x) for x in res.stdout.strip().splitlines()]
+    line = lines[-1]
+    assert [x["frame"] for x in lines[:-1]] == [0, 1, 2, 3, 4]
+    assert line["n_gpus"] == 4 and line["steps"] == 3 and line["warmup"] == 2 and line["unit"] == "Mray/s"
+    assert line["ms_per_step"] > 0 and abs(line["value"] - 300 * 200 * 10 * 50 / (line["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * line["value"]
+    cfg = line["config"]
+    assert cfg["transport"] == "peer-copy" and cfg["devices"] == [0, 0, 0, 0] and cfg["frames_in_flight"] == 1
+    assert len(cfg["device_kernel_ms"]) == 4 and all(t > 0 for t in cfg["device_kernel_ms"])
+    assert cfg["gathered_frame_vs_single_gpu_frame"] == "identical"
+    assert cfg["frame_crc32"] == gold["crc32"] and cfg["segments_per_frame"] == gold["segments"]
+
+
 def test_rccl_bindings_with_a_communicator_of_one(oracle, tmp_path):
     """RTIOW_MULTI_TRANSPORT=rccl with one device: librccl.so.1 is opened, ncclCommInitAll makes a one-rank communicator
     and every frame goes through ncclGroupStart / ncclGather (in place) / ncclGroupEnd and the de-interleave kernel.

@@ -65,6 +65,32 @@ def test_ch_kernels_bit_exact(gpu_ctx, oracle, mode, w, h):
     assert st.bytes_written == want.shape[0] * want.shape[1] * 4 and st.kernel_ms > 0
 
 
+@pytest.mark.parametrize("mode", [V.RT_MODE_CH05, V.RT_MODE_CH06])
+def test_ch_row_kernel_equals_the_tiled_form_and_the_oracle(gpu_ctx, oracle, mode):
+    """ch_kernel_rows (four pixels of a row per lane, per-column / per-row terms hoisted into LDS, 16-byte stores) against
+    ch_kernel_tiles (RtParams.kernel = 1: one lane per pixel in 16x16 tiles, statement for statement raytrace06.comp) and
+    against the oracle: widths around the 256-column tile and the 4-pixel quad, heights around the rows of a workgroup,
+    one-row and one-column images (u or v is 0/0: the tiled form takes them), and a device destination whose pitch makes
+    the rows 4- but not 16-byte aligned (scalar stores instead of the 16-byte one)."""
+    import torch
+    for w, h in ((255, 3), (256, 4), (257, 5), (258, 2), (2, 2), (3, 2), (5, 1), (1, 5), (1023, 7), (1027, 65), (1200, 800),
+                 (4099, 130)):
+        rows = gpu_ctx.render(None, V.make_params(w, h, mode=mode))
+        tiles = gpu_ctx.render(None, V.make_params(w, h, mode=mode, kernel=V.KERNEL_PIXEL))
+        want = oracle.render_ubo(oracle.ubo_from_image(w, h), mode)
+        assert np.array_equal(rows, tiles), (w, h, _diff(rows, tiles))
+        assert np.array_equal(rows, want), (w, h, _diff(rows, want))
+    w, h = 1026, 33
+    want = oracle.render_ubo(oracle.ubo_from_image(w, h), mode)
+    for pad in (1, 2, 3, 4):  # pitch = (w + pad) words
+        buf = torch.full((h, w + pad), 0x55555555, dtype=torch.int32, device="cuda")
+        gpu_ctx.render_device(None, V.make_params(w, h, mode=mode), buf.data_ptr(), (w + pad) * 4, 0)
+        gpu_ctx.synchronize()
+        got = buf.cpu().numpy()
+        assert (got[:, w:] == 0x55555555).all(), pad  # nothing written past the row
+        assert np.array_equal(got[:, :w].copy().view(np.uint8).reshape(h, w, 4), want), pad
+
+
 def test_ch_known_answers_on_gpu(gpu_ctx):
     """SURVEY 8(c) table straight against the HIP kernel (no oracle in the loop)."""
     for row in json.load(open(os.path.join(GOLD, "ch_known_answers.json"))):

@@ -277,6 +277,7 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         a.height = H;
         a.dst = out;
         a.dst_stride = out_stride;
+        a.tiles_form = prm->kernel == rtiow::KERNEL_PIXEL ? 1u : 0u;
         RT_HIP(ctx, rtiow::launch_ch(a, stream));
     } else {
         rtiow::PathArgs a{};
@@ -425,6 +426,7 @@ int rtRender(RtContext* ctx, const RtCamera* cam, const RtParams* params, void* 
         p.height = params->height;
         p.mode = params->mode;
         p.spp = 1;
+        p.kernel = params->kernel == rtiow::KERNEL_PIXEL ? params->kernel : 0u;  // (1: one lane per pixel in 16x16 tiles, the reference's dispatch shape)
         return render_common(ctx, true, &ubo, nullptr, &p, dst, dst_pitch, dst_is_device, stream);
     }
     if (params->mode != RT_MODE_PATH) return fail(ctx, RT_ERR_INVALID, "rtRender: unknown mode");

@@ -103,6 +103,9 @@ struct ChArgs {
     uint32_t width, height;
     uint32_t* dst;
     uint32_t dst_stride;
+    uint32_t tiles_form;     // != 0: one lane per pixel in 16x16 tiles, as the reference dispatches (RtParams.kernel = 1)
+    uint32_t rows_per_wave;  // (set by launch_ch) rows of the frame a wave of ch_kernel_rows renders
+    uint32_t vector_store;   // (set by launch_ch) destination rows are 16-byte aligned
 };
 
 // kernel variants selectable through RtParams.kernel (identical results)

@@ -1,8 +1,10 @@
 // rtiow_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the
 // per-pixel path-tracing hot path.
 //
-//   ch_kernel               raytrace05.comp / raytrace06.comp (the reference's two compute shaders), one lane
-//                           per pixel, packed RGBA8 store
+//   ch_kernel_rows          raytrace05.comp / raytrace06.comp (the reference's two compute shaders): four pixels of a row
+//                           per lane, per-column / per-row terms shared through LDS, 16-byte stores
+//   ch_kernel_tiles         the same, one lane per pixel in 16x16 tiles as the reference dispatches them (degenerate
+//                           image sizes; RtParams.kernel = 1: the form the row kernel is checked against)
 //   path_pixel_kernel       PATH mode v1 (RtParams.kernel 1): one lane per pixel, spp + bounce loops inside, sphere
 //                           list staged in LDS once per workgroup; kept as a cross-check and ablation
 //   path_persistent_kernel  PATH mode v2, four instantiations <shading records in LDS?, clustered list?>: persistent
@@ -113,11 +115,12 @@ DI f3 gnormalize(f3 a) {
 }
 
 #ifndef RTIOW_TU_SMALL_CLUSTERED
-// 16x16 workgroup as raytrace06.comp:2; ceil-div grid with a bounds check
-// (fixes the fixed 64x64 / floor-div dispatches of main.cpp:321 and
-// RTCHAP05 main.cpp:306).  One packed 32-bit store per lane: a wave writes
-// four 64-byte row segments.
-__global__ __launch_bounds__(256) void ch_kernel(ChArgs a) {
+// ch_kernel_tiles: the shaders as the reference dispatches them -- 16x16 workgroup as raytrace06.comp:2, one lane per
+// pixel; ceil-div grid with a bounds check (fixes the fixed 64x64 / floor-div dispatches of main.cpp:321 and RTCHAP05
+// main.cpp:306).  One packed 32-bit store per lane: a wave writes four 64-byte row segments.  Kept for degenerate images
+// (one row or one column: u or v is 0/0 there, and the row kernel below relies on them being finite) and as the
+// statement-for-statement form the row kernel is checked against (tests: RtParams.kernel = 1 selects it).
+__global__ __launch_bounds__(256) void ch_kernel_tiles(ChArgs a) {
     const uint32_t tiles_x = (a.width + 15u) / 16u;
     const uint32_t gx = (blockIdx.x % tiles_x) * 16u + (threadIdx.x & 15u);
     const uint32_t gy = (blockIdx.x / tiles_x) * 16u + (threadIdx.x >> 4);
@@ -180,6 +183,138 @@ __global__ __launch_bounds__(256) void ch_kernel(ChArgs a) {
     // imageStore(vec4(color,0.0)) into rgba8: alpha byte 0 (raytrace06.comp:66)
     a.dst[static_cast<size_t>(gy) * a.dst_stride + gx] =
         pack_rgb(quant_unorm8(col.x), quant_unorm8(col.y), quant_unorm8(col.z));
+}
+
+
+// ch_kernel_rows: the same arithmetic, laid out for the memory system.  At 4 bytes per pixel the shaders should be
+// bound by HBM writes, but one lane per pixel spends ~200 IEEE-exact instructions on each (round 2: 1.44 TB/s, 18 % of
+// the 8 TB/s peak, at 16384^2).  Two observations cut that to ~60 for a sky pixel and ~100 for a sphere pixel without
+// changing one rounding:
+//   * raytrace06.comp:57-61 makes dir.x a function of the COLUMN only, dir.y of the ROW only and dir.z a constant
+//     (horizontal = (w,0,0), vertical = (0,h,0): the cross terms are 0 * u and 0 * v, +0 for the finite, non-negative
+//     u, v of an image with at least two rows and columns).  So dir.x, dir.x*dir.x and oc.x*dir.x are computed once per
+//     column of a 256-column tile and dir.y, dir.y*dir.y, oc.y*dir.y once per row, by the very expressions of the
+//     shader, and shared through LDS; per pixel, gdot(dir,dir) = (xx + yy) + zz is two additions of the SAME three
+//     products the per-pixel form adds -- same operands, same order, same roundings;
+//   * normalize(dir) is only ever read for its y component (raytrace06.comp:45-46): one division instead of three.
+// A lane takes four consecutive pixels of a row and writes them with one 16-byte store: a wave writes 1 KB of one row
+// (eight whole 128-byte lines), a workgroup 4 x rows_per_wave rows of the same 256 columns, whose per-column values
+// stay in registers from row to row.
+struct ChConst {  // per-frame constants of raytrace06.comp:53-56, 21-27, by the shader's own expressions
+    float hx, vy, llc_x, llc_y, dz, zz, oz_dz, oc_x, oc_y, qc;
+};
+DI ChConst ch_constants(const RtUbo5& ubo) {
+    const f3 origin = mk(0.0f, 0.0f, 0.0f);
+    const f3 horizontal = mk(ubo.viewportWidth, 0.0f, 0.0f);
+    const f3 vertical = mk(0.0f, ubo.viewportHeight, 0.0f);
+    ChConst k;
+    k.hx = horizontal.x;
+    k.vy = vertical.y;
+    k.llc_x = ((origin.x - horizontal.x / 2) - vertical.x / 2) - 0.0f;
+    k.llc_y = ((origin.y - horizontal.y / 2) - vertical.y / 2) - 0.0f;
+    const float llc_z = ((origin.z - horizontal.z / 2) - vertical.z / 2) - ubo.focalLength;
+    // dir.z = ((llc.z + horizontal.z * u) + vertical.z * v) - origin.z with horizontal.z * u = vertical.z * v = +0
+    k.dz = ((llc_z + 0.0f) + 0.0f) - origin.z;
+    const f3 centre = mk(0.0f, 0.0f, -1.0f);
+    const float radius = 0.5f;
+    const f3 oc = mk(origin.x - centre.x, origin.y - centre.y, origin.z - centre.z);
+    k.oc_x = oc.x;
+    k.oc_y = oc.y;
+    k.zz = k.dz * k.dz;
+    k.oz_dz = oc.z * k.dz;
+    k.qc = gdot(oc, oc) - radius * radius;
+    return k;
+}
+
+// quant_unorm8 in four instructions: (int)(clamp(x, 0, 1) * 255 + 0.5) == min(u32(x * 255 + 0.5), 255) for every float x,
+// the conversion being v_cvt_u32_f32 -- truncation toward zero, negative values and NaN to 0, overflow to 2^32 - 1: below
+// 0 the clamp gives 0.5 -> 0 and the conversion 0; inside [0, 1] the two expressions are the same float; above 1 the clamp
+// gives 255.5 -> 255 and the conversion something >= 255, which the integer minimum brings back.  (Written as asm: a C cast
+// of an out-of-range float is undefined, the instruction is not.)
+DI uint32_t ch_unorm8(float x) {
+    const float y = x * 255.0f + 0.5f;
+    uint32_t q;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(y));
+    return q < 255u ? q : 255u;
+}
+
+// one pixel: raytrace06.comp:21-48 / raytrace05.comp:21-40 from the hoisted products (xx = dir.x*dir.x, ox = oc.x*dir.x, ...)
+DI uint32_t ch_pixel(uint32_t mode, const ChConst& k, float dx, float xx, float ox, float dy, float yy, float oy) {
+    const float qa = (xx + yy) + k.zz;             // gdot(dir, dir)
+    const float qb = 2.0f * ((ox + oy) + k.oz_dz);   // 2 * gdot(oc, dir)
+    const float disc = qb * qb - 4 * qa * k.qc;
+    f3 col;
+    bool shaded = false;
+    if (mode == RT_MODE_CH05) {
+        if (disc > 0) {  // raytrace05.comp:29,35-37
+            col = mk(1.0f, 0.0f, 0.0f);
+            shaded = true;
+        }
+    } else {
+        const float t = (disc < 0) ? -1.0f : (-qb - __builtin_sqrtf(disc)) / (2.0f * qa);
+        if (t > 0.0f) {  // raytrace06.comp:39-43
+            const f3 r = mk(0.0f + dx * t, 0.0f + dy * t, 0.0f + k.dz * t);
+            const f3 nrm = gnormalize(mk(r.x - 0.0f, r.y - 0.0f, r.z - (-1.0f)));
+            col = mk(0.5f * (nrm.x + 1), 0.5f * (nrm.y + 1), 0.5f * (nrm.z + 1));
+            shaded = true;
+        }
+    }
+    if (!shaded) {  // raytrace06.comp:45-47: only the y component of normalize(dir) is used
+        const float unit_y = dy / __builtin_sqrtf(qa);
+        const float t = 0.5f * (unit_y + 1.0f);
+        const float kk = 1.0f - t;
+        col = mk(1.0f * kk + 0.5f * t, 1.0f * kk + 0.7f * t, 1.0f * kk + 1.0f * t);
+    }
+    return pack_rgb(ch_unorm8(col.x), ch_unorm8(col.y), ch_unorm8(col.z));  // alpha byte 0 (raytrace06.comp:66)
+}
+
+constexpr uint32_t kChTileCols = 256;  // columns of a workgroup's tile: 64 lanes x 4 pixels
+__global__ __launch_bounds__(256) void ch_kernel_rows(ChArgs a) {
+    __shared__ float4 col_dx[kChTileCols / 4], col_xx[kChTileCols / 4], col_ox[kChTileCols / 4];  // per column, four to a lane
+    __shared__ float row_dy[64], row_yy[64], row_oy[64];                                          // per row of the tile
+    const ChConst k = ch_constants(a.ubo);
+    const uint32_t tiles_x = (a.width + kChTileCols - 1u) / kChTileCols;
+    const uint32_t rows_per_block = 4u * a.rows_per_wave;  // (<= 64)
+    const uint32_t col0 = (blockIdx.x % tiles_x) * kChTileCols, row0 = (blockIdx.x / tiles_x) * rows_per_block;
+    {   // raytrace06.comp:57,59: u and dir.x of this thread's column (0 * v = +0: v is finite and >= 0)
+        const float u = static_cast<float>(col0 + threadIdx.x) / (a.ubo.imageWidth - 1);
+        const float dx = ((k.llc_x + k.hx * u) + 0.0f) - 0.0f;
+        reinterpret_cast<float*>(col_dx)[threadIdx.x] = dx;
+        reinterpret_cast<float*>(col_xx)[threadIdx.x] = dx * dx;
+        reinterpret_cast<float*>(col_ox)[threadIdx.x] = k.oc_x * dx;
+    }
+    if (threadIdx.x < rows_per_block) {  // raytrace06.comp:58,60: v and dir.y of the tile's rows (0 * u = +0)
+        const float v = static_cast<float>(row0 + threadIdx.x) / (a.ubo.imageHeight - 1);
+        const float dy = ((k.llc_y + 0.0f) + k.vy * v) - 0.0f;
+        row_dy[threadIdx.x] = dy;
+        row_yy[threadIdx.x] = dy * dy;
+        row_oy[threadIdx.x] = k.oc_y * dy;
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t c = col0 + 4u * lane;
+    if (c >= a.width) return;
+    const float4 dx4 = col_dx[lane], xx4 = col_xx[lane], ox4 = col_ox[lane];
+    const bool vec = c + 3u < a.width && a.vector_store != 0u;  // a whole, 16-byte aligned quad
+    for (uint32_t j = 0; j < a.rows_per_wave; ++j) {
+        const uint32_t lr = wave * a.rows_per_wave + j, row = row0 + lr;
+        if (row >= a.height) break;
+        const float dy = row_dy[lr], yy = row_yy[lr], oy = row_oy[lr];  // LDS broadcast
+        uint4 px;
+        px.x = ch_pixel(a.mode, k, dx4.x, xx4.x, ox4.x, dy, yy, oy);
+        px.y = ch_pixel(a.mode, k, dx4.y, xx4.y, ox4.y, dy, yy, oy);
+        px.z = ch_pixel(a.mode, k, dx4.z, xx4.z, ox4.z, dy, yy, oy);
+        px.w = ch_pixel(a.mode, k, dx4.w, xx4.w, ox4.w, dy, yy, oy);
+        uint32_t* out = a.dst + static_cast<size_t>(row) * a.dst_stride + c;
+        if (vec) {
+            *reinterpret_cast<uint4*>(out) = px;
+        } else {  // the ragged right edge, or a destination that is not 16-byte aligned
+            out[0] = px.x;
+            if (c + 1u < a.width) out[1] = px.y;
+            if (c + 2u < a.width) out[2] = px.z;
+            if (c + 3u < a.width) out[3] = px.w;
+        }
+    }
 }
 
 #endif  // RTIOW_TU_SMALL_CLUSTERED
@@ -2509,9 +2644,23 @@ hipError_t launch_order_chunks(unsigned long long* cost, uint32_t* order, uint32
     return hipGetLastError();
 }
 
-hipError_t launch_ch(const ChArgs& a, hipStream_t stream) {
-    const uint32_t tiles = ((a.width + 15u) / 16u) * ((a.height + 15u) / 16u);
-    hipLaunchKernelGGL(ch_kernel, dim3(tiles), dim3(256), 0, stream, a);
+hipError_t launch_ch(const ChArgs& args, hipStream_t stream) {
+    ChArgs a = args;
+    // one row or one column (u or v is 0/0), or the tiled form asked for: one lane per pixel, as the reference dispatches it
+    if (a.width < 2u || a.height < 2u || a.tiles_form != 0u) {
+        const uint32_t tiles = ((a.width + 15u) / 16u) * ((a.height + 15u) / 16u);
+        hipLaunchKernelGGL(ch_kernel_tiles, dim3(tiles), dim3(256), 0, stream, a);
+        return hipGetLastError();
+    }
+    // rows a wave renders: enough workgroups to fill the chip eight times over first (the reference's 800x608 frame is
+    // launch-bound: 4 rows per workgroup, 608 workgroups), then up to 16 so that the per-column values are reused
+    const uint32_t tiles_x = (a.width + kChTileCols - 1u) / kChTileCols;
+    uint32_t rpw = 1u;
+    while (rpw < 16u && static_cast<unsigned long long>(tiles_x) * ((a.height + 8u * rpw - 1u) / (8u * rpw)) >= 2048ull) rpw *= 2u;
+    a.rows_per_wave = rpw;
+    a.vector_store = (reinterpret_cast<uintptr_t>(a.dst) % 16u == 0u && a.dst_stride % 4u == 0u) ? 1u : 0u;
+    const uint32_t blocks = tiles_x * ((a.height + 4u * rpw - 1u) / (4u * rpw));
+    hipLaunchKernelGGL(ch_kernel_rows, dim3(blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

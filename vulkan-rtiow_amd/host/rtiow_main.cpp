@@ -8,7 +8,12 @@
 //              --device G | --gpus N | --devices g0,g1,... --json 0|1]
 //
 // --json 1 prints one JSON object per frame (W, H, spp, depth, spheres, GPUs, kernel and wall ms, nominal Mray/s, segments,
-// sphere tests: the metrics line SURVEY section 5 asks of the harness; the reference logs nothing) instead of the text.
+// sphere tests: the metrics line SURVEY section 5 asks of the harness; the reference logs nothing) instead of the text,
+// and after the last frame one summary object with bench.py's fields -- metric, value, n_gpus, steps, warmup (--warmup W
+// of the F frames are left out of it), ms_per_step, and under "config" the transport, every device's tile kernel ms,
+// the frame's CRC-32 and, on the multi-GPU path, whether the gathered frame is the one device 0 renders alone -- so the
+// C-ABI path (rtMultiRender) is timed by the same yardstick as the torch path:
+//     rtiow_main --gpus 8 --frames 12 --warmup 2 --json 1        (rehearsal on one GPU: --devices 0,0,0,0,0,0,0,0)
 //
 // --gpus N renders every frame on devices 0..N-1 of this node from this one process (rtCreateMulti: block-cyclic
 // row tiles, one RCCL gather to device 0, de-interleave there); --devices names them (a repeated device is the
@@ -32,6 +37,19 @@
 #include "scene_file.h"
 
 namespace {
+uint32_t crc32_of(const uint8_t* p, size_t n) {  // zlib's CRC-32 (reflected 0xEDB88320), as tests/golden/frame_golden.json holds it
+    static uint32_t table[256];
+    if (table[1] == 0u)
+        for (uint32_t i = 0; i < 256u; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
 int die(RtContext* ctx, const char* what, int rc) {
     std::fprintf(stderr, "%s failed (%d): %s\n", what, rc, rtGetLastError(ctx));
     if (ctx) rtDestroy(ctx);
@@ -41,7 +59,7 @@ int die(RtContext* ctx, const char* what, int rc) {
 
 int main(int argc, char** argv) {
     std::string scene = "cover", out = "frame.ppm", file;
-    uint32_t width = 1200, height = 800, spp = 100, depth = 50, seed = 1, kernel = 0, frames = 1, progressive = 0, json = 0;
+    uint32_t width = 1200, height = 800, spp = 100, depth = 50, seed = 1, kernel = 0, frames = 1, progressive = 0, json = 0, warmup = 0;
     uint32_t n_spheres = 1;
     int device = 0;
     std::vector<int> devices;  // --gpus / --devices: the multi-GPU path
@@ -60,6 +78,7 @@ int main(int argc, char** argv) {
         else if (k == "--file") file = v;
         else if (k == "--json") json = std::strtoul(v, nullptr, 10);
         else if (k == "--frames") frames = std::strtoul(v, nullptr, 10);
+        else if (k == "--warmup") warmup = std::strtoul(v, nullptr, 10);
         else if (k == "--device") device = std::atoi(v);
         else if (k == "--gpus") { devices.clear(); for (int g = 0; g < std::atoi(v); ++g) devices.push_back(g); }
         else if (k == "--devices") {
@@ -127,6 +146,10 @@ int main(int argc, char** argv) {
     }
 
     std::vector<uint8_t> frame(size_t(width) * height * 4);
+    if (warmup >= frames) warmup = frames ? frames - 1 : 0;
+    double sum_frame_ms = 0.0, sum_wall_ms = 0.0;  // over the frames after the warm-up
+    std::vector<double> sum_dev_ms(devices.empty() ? 1 : devices.size(), 0.0);
+    unsigned long long last_segments = 0, last_tests = 0;
     for (uint32_t f = 0; f < frames; ++f) {  // the frame loop of main.cpp:304-360
         const auto t0 = std::chrono::steady_clock::now();
         if (progressive && prm.mode == RT_MODE_PATH) {  // running average over the frames so far
@@ -148,13 +171,21 @@ int main(int argc, char** argv) {
             for (int g = 0; g < rtMultiDeviceCount(multi); ++g) {
                 if ((rc = rtMultiGetStats(multi, g, &part, &frame_ms)) != RT_OK) return die_multi("rtMultiGetStats", rc);
                 if (!json) std::printf("  device %d: tile kernel %.3f ms, %u rows\n", devices[g], part.kernel_ms, part.rows_rendered);
+                if (f >= warmup) sum_dev_ms[g] += part.kernel_ms;
                 st.segments += part.segments;
                 st.sphere_tests += part.sphere_tests;
             }
             st.kernel_ms = frame_ms;
         } else {
             rtGetStats(ctx, &st);
+            if (f >= warmup) sum_dev_ms[0] += st.kernel_ms;
         }
+        if (f >= warmup) {
+            sum_frame_ms += st.kernel_ms;
+            sum_wall_ms += wall;
+        }
+        last_segments = st.segments;
+        last_tests = st.sphere_tests;
         const double nominal = double(width) * height * (prm.mode == RT_MODE_PATH ? double(spp) * depth : 1.0);
         if (json)
             std::printf("{\"frame\": %u, \"scene\": \"%s\", \"width\": %u, \"height\": %u, \"spp\": %u, \"max_depth\": %u, "
@@ -167,6 +198,55 @@ int main(int argc, char** argv) {
             std::printf("frame %u: kernel %.3f ms, wall %.3f ms, %.1f Mray/s nominal, %llu segments, %llu sphere tests\n",
                         f, st.kernel_ms, wall, nominal / (st.kernel_ms * 1e-3) / 1e6,
                         (unsigned long long)st.segments, (unsigned long long)st.sphere_tests);
+    }
+    if (json && frames > 0) {
+        // the summary line: bench.py's fields for this path.  ms_per_step = device-side time of a frame, one frame in flight
+        // (single GPU: the dispatch; several: first launch to assembled frame on the root); wall adds the copy to the host.
+        const uint32_t steps = frames - warmup;
+        const double ms = sum_frame_ms / steps;
+        const double nominal = double(width) * height * (prm.mode == RT_MODE_PATH ? double(spp) * depth : 1.0);
+        const uint32_t crc = crc32_of(frame.data(), frame.size());
+        const char* vs_single = "not checked";
+        if (multi && devices.size() > 1 && !progressive) {  // the same frame by device 0 alone, through the single-GPU entry point
+            RtContext* one = nullptr;
+            std::vector<uint8_t> whole(frame.size());
+            bool ok = rtCreate(devices[0], &one) == RT_OK;
+            if (ok && prm.mode == RT_MODE_PATH) {
+                std::vector<RtSphere> sph(5000);
+                std::vector<RtMaterial> mat(5000);
+                uint32_t n = 0;
+                if (scene == "file") {
+                    bool have_cam = false;
+                    RtCamera c2{};
+                    sph.clear();
+                    mat.clear();
+                    ok = load_scene_file(file, float(width) / float(height), sph, mat, c2, have_cam);
+                    n = static_cast<uint32_t>(sph.size());
+                } else if (scene == "three") {
+                    ok = rtMakeThreeSphereScene(1, sph.data(), mat.data(), 5000, &n) == RT_OK;
+                } else {
+                    ok = rtMakeCoverScene(seed, scene == "cover4096" ? 32 : 11, sph.data(), mat.data(), 5000, &n) == RT_OK;
+                }
+                ok = ok && rtSetScene(one, sph.data(), mat.data(), n) == RT_OK;
+            }
+            ok = ok && rtRender(one, &cam, &prm, whole.data(), size_t(width) * 4, 0, nullptr) == RT_OK;
+            vs_single = !ok ? "single-GPU render failed" : (whole == frame ? "identical" : "DIFFERS");
+            rtDestroy(one);
+        }
+        std::printf("{\"metric\": \"Mray/s (w*h*spp*depth / s)\", \"value\": %.1f, \"unit\": \"Mray/s\", \"n_gpus\": %d, \"steps\": %u, "
+                    "\"warmup\": %u, \"ms_per_step\": %.4f, \"higher_is_better\": true, \"scaling\": \"strong\", \"dtype\": \"f32\", "
+                    "\"data\": \"synthetic\", \"config\": {\"workload\": \"%s_%ux%u_%uspp\", \"path\": \"C ABI, one process: %s\", "
+                    "\"transport\": \"%s\", \"frames_in_flight\": 1, \"destination\": \"host memory\", \"wall_ms_per_step\": %.4f, "
+                    "\"device_kernel_ms\": [",
+                    nominal / (ms * 1e-3) / 1e6, multi ? rtMultiDeviceCount(multi) : 1, steps, warmup, ms, scene.c_str(), width, height,
+                    prm.mode == RT_MODE_PATH ? spp : 1u, multi ? "rtMultiRender" : "rtRender", multi ? rtMultiTransport(multi) : "single",
+                    sum_wall_ms / steps);
+        for (size_t g = 0; g < sum_dev_ms.size(); ++g) std::printf("%s%.4f", g ? ", " : "", sum_dev_ms[g] / steps);
+        std::printf("], \"devices\": [");
+        for (size_t g = 0; g < sum_dev_ms.size(); ++g) std::printf("%s%d", g ? ", " : "", devices.empty() ? device : devices[g]);
+        std::printf("], \"segments_per_frame\": %llu, \"sphere_tests_per_frame\": %llu, \"frame_crc32\": %u, "
+                    "\"gathered_frame_vs_single_gpu_frame\": \"%s\"}}\n",
+                    last_segments, last_tests, crc, vs_single);
     }
     const bool png = out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0;
     rc = png ? rtWritePNG(out.c_str(), frame.data(), width, height, size_t(width) * 4)
