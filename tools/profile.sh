@@ -22,6 +22,6 @@ rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_WAVES GR
 #   4. lane occupancy of the vector instructions: SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU), and the rest of the mix
 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_INSTS_LDS_ATOMIC \
     --output-format csv -d $O/prof_${TAG}_lane -- $BENCH > $O/prof_${TAG}_lane.log 2>&1 || true
-#   5. the reference's own kernel at a size where bytes matter: 16384^2 CH06 frames
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_ch -- python3 $R/tools/ch_bandwidth.py > $O/prof_${TAG}_ch.log 2>&1 || true
 cd $R && python3 tools/profile_summary.py $TAG
+#   5. the reference's own kernels at sizes where bytes matter: kernel stats + PMC passes of tools/ch_bandwidth.py
+bash $R/tools/pmc_ch.sh $TAG || true

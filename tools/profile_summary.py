@@ -83,11 +83,6 @@ if kt:
     json.dump({"path_kernel_ms_per_launch": d, "warmup_launches": warm, "mean_ms_of_timed_launches": sum(timed) / max(1, len(timed)),
                "bench_event_ms_same_run": (bench_line or {}).get("config", {}).get("kernel_ms_rank0")},
               open(os.path.join(prof, f"{tag}_kernel_launches.json"), "w"), indent=1)
-chs = one(f"prof_{tag}_ch/**/*_kernel_stats.csv")
-if chs:
-    shutil.copy(chs, os.path.join(prof, f"{tag}_ch_kernel_stats.csv"))
-    chlog = os.path.join(out, f"prof_{tag}_ch.log")
-    if os.path.exists(chlog):
-        shutil.copy(chlog, os.path.join(prof, f"{tag}_ch_bandwidth.txt"))
+# (the reference's own kernels: tools/pmc_ch.sh + tools/pmc_ch_summary.py)
 print("kernel stats:", open(os.path.join(prof, f"{tag}_kernel_stats.csv")).read() if ks else "missing")
 print("traffic:", traffic)

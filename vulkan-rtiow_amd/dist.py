@@ -72,7 +72,8 @@ def transport_label(group=None) -> str:
         return "single process, no collective"
     backend = dist.get_backend(group)
     name = {"nccl": "RCCL (torch backend nccl)", "gloo": "gloo (CPU rehearsal, frames staged through host memory)"}.get(backend, backend)
-    return f"{name} {'ncclGather-style dist.gather to rank 0' if collective() == 'gather' else 'all_gather_into_tensor'}, {dist.get_world_size(group)} ranks"
+    how = "dist.gather to rank 0" if collective() == "gather" else "dist.all_gather_into_tensor"
+    return f"{name}, {how}, {dist.get_world_size(group)} ranks"
 
 
 def gather_frame(local: torch.Tensor, height: int, row_block: int, rank: int, world: int,
