@@ -194,3 +194,36 @@ def test_primary_pass_extreme_cameras(gpu_ctx, oracle, case):
             tiled[rows] = gpu_ctx.render(cam, V.make_params(w, h, kernel=V.KERNEL_CLUSTERED_PASS, row_block=2, tile_rank=r,
                                                             tile_count=3, **base))
     assert np.array_equal(tiled, want), case
+
+
+@pytest.mark.parametrize("up_axis", [0, 1, 2])
+def test_flat_axis_box_test_equals_whole_boxes(oracle, monkeypatch, up_axis):
+    """The clustered kernels test a scene's cluster boxes without their flat axis when all boxes span (nearly) one interval
+    along it (spheres on a ground plane: rtiow_clusters.cpp, slab_gap_flat).  A layer of spheres lying in each of the
+    three coordinate planes in turn (flat axis 0, 1, 2), small (clusters only) and large (super-clusters too), rendered
+    with the flat test, with whole boxes (RTIOW_DEBUG_FLAT=0) and -- a scene that is NOT flat -- with the flat test forced
+    on (RTIOW_DEBUG_FLAT=1: conservative, only slower): all equal to the oracle's frame."""
+    for n, cubic in ((300, False), (2600, False), (500, True)):
+        rng = np.random.default_rng(77 + n + up_axis)
+        sph, mat = _random_scene(rng, n, 1.0)
+        pos = np.stack([sph["cx"], rng.uniform(-0.004, 0.004, n) if not cubic else rng.uniform(-1, 1, n), sph["cz"]], 1)
+        sph["radius"] = np.sign(sph["radius"]) * rng.uniform(0.05, 0.06, n)  # (no ground sphere; radii alike, so that a layer is flat)
+        pos = np.roll(pos, up_axis - 1, axis=1)  # the layer's normal along up_axis
+        sph["cx"], sph["cy"], sph["cz"] = pos[:, 0], pos[:, 1], pos[:, 2]
+        w, h = 64, 40
+        frm = np.roll(np.array([2.5, 1.2, 1.9]), up_axis - 1)
+        cam = V.make_camera(tuple(frm), (0.0, 0.0, 0.0), tuple(np.roll(np.array([0.0, 1.0, 0.0]), up_axis - 1)), 40.0, w / h, 0.05, 3.0)
+        base = dict(spp=3, max_depth=12, seed=5)
+        want, segs = oracle.render(sph, mat, cam, V.make_params(w, h, **base))
+        tests = {}
+        for mode in ("0", "1", "2"):  # whole boxes; flat forced; the library's own choice
+            monkeypatch.setenv("RTIOW_DEBUG_FLAT", mode)
+            with V.Context(0) as ctx:
+                ctx.set_scene(sph, mat)
+                for kernel in (V.KERNEL_CLUSTERED, V.KERNEL_CLUSTERED_PASS):
+                    got = ctx.render(cam, V.make_params(w, h, kernel=kernel, **base))
+                    st = ctx.stats()
+                    assert np.array_equal(got, want) and st.segments == segs, (n, cubic, up_axis, mode, kernel)
+                    tests[mode, kernel] = st.sphere_tests
+        # (which boxes a ray is tested against differs between the modes, the frame must not: asserted above for every mode)
+        assert all(v > 0 for v in tests.values())

@@ -146,6 +146,9 @@ static int upload_clusters(RtContext* ctx, double range_diags) {
     ctx->n_large = cs.n_large;
     ctx->n_large_slots = cs.n_large_slots;
     ctx->n_cslots = static_cast<uint32_t>(cs.slots.size());
+    ctx->flat_axis = cs.flat_axis;
+    ctx->flat_mid = cs.flat_mid;
+    ctx->flat_half = cs.flat_half;
     for (int k = 0; k < 3; ++k) ctx->cluster_center[k] = cs.center[k];
     ctx->cluster_diag = cs.diag;
     ctx->cluster_rmax2 = cs.rmax2;
@@ -291,6 +294,10 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         a.n_large = ctx->n_large;
         a.n_large_slots = ctx->n_large_slots;
         a.n_cslots = ctx->n_cslots;
+        a.flat_axis = ctx->flat_axis;
+        a.cbounds2 = ctx->d_cbounds + 2u * size_t(ctx->n_clusters + ctx->n_super);
+        a.flat_mid = ctx->flat_mid;
+        a.flat_half = ctx->flat_half;
         for (int k = 0; k < 3; ++k) a.ccenter[k] = ctx->cluster_center[k];
         a.crmax2 = ctx->cluster_rmax2;
         a.n = ctx->n_spheres;
@@ -347,6 +354,10 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
                 a.n_large = ctx->n_large;
                 a.n_large_slots = ctx->n_large_slots;
                 a.n_cslots = ctx->n_cslots;
+                a.flat_axis = ctx->flat_axis;
+        a.cbounds2 = ctx->d_cbounds + 2u * size_t(ctx->n_clusters + ctx->n_super);
+                a.flat_mid = ctx->flat_mid;
+                a.flat_half = ctx->flat_half;
                 for (int k = 0; k < 3; ++k) a.ccenter[k] = ctx->cluster_center[k];
                 a.crmax2 = ctx->cluster_rmax2;
             }

@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <numeric>
 #include <vector>
 
@@ -192,6 +193,46 @@ void build_clusters(const RtSphere* sph, uint32_t n, double range_diags, Cluster
             }
             out.bounds.push_back(mid);
             out.bounds.push_back(half);
+        }
+    }
+    // The flat axis.  Scenes of this renderer mostly stand on a ground plane: every cluster box then spans (nearly) the
+    // same interval along the up axis, and the kernel's slab test can take that axis ONCE per ray against the common
+    // interval instead of once per box (rtiow_kernels.hip: slab_gap_flat, 10 instead of 14 instructions per ray and box,
+    // one 16-byte LDS read per box instead of two).  A wider interval only ever lets more boxes through, so using the
+    // union of the boxes' intervals is conservative by construction; it is taken when no real box is narrower than two
+    // thirds of the union (the cull would lose too much otherwise) along the best such axis.
+    out.flat_axis = 3u;
+    out.flat_mid = out.flat_half = 0.0f;
+    if (n_real_clusters > 0u) {
+        const char* force = std::getenv("RTIOW_DEBUG_FLAT");  // (1: every scene flat along its best axis -- parity tests only)
+        double best_ratio = force && std::atoi(force) == 1 ? 1e300 : 1.5;
+        for (uint32_t axis = 0; axis < 3u; ++axis) {
+            double lo = 1e300, hi = -1e300, narrowest = 1e300;
+            for (size_t c = 0; c < n_real_clusters; ++c) {
+                const ClusterF4 &mid = out.bounds[2u * c], &half = out.bounds[2u * c + 1u];
+                const double m = axis == 0 ? mid.x : (axis == 1 ? mid.y : mid.z), h = axis == 0 ? half.x : (axis == 1 ? half.y : half.z);
+                lo = std::min(lo, m - h);
+                hi = std::max(hi, m + h);
+                narrowest = std::min(narrowest, 2.0 * h);
+            }
+            const double ratio = (hi - lo) / std::max(narrowest, 1e-300);
+            if (ratio <= best_ratio) {
+                best_ratio = ratio;
+                out.flat_axis = axis;
+                out.flat_mid = static_cast<float>(0.5 * (lo + hi));
+                out.flat_half = round_up(std::max(hi - double(out.flat_mid), double(out.flat_mid) - lo));
+            }
+        }
+    }
+    // the boxes again without the flat axis, one float4 {mid a, mid b, half a, half b} each (a, b: the other two axes in
+    // x, y, z order), clusters then super-clusters: appended to `bounds` behind the full boxes
+    if (out.flat_axis < 3u) {
+        const size_t n_boxes = out.bounds.size() / 2u;
+        for (size_t c = 0; c < n_boxes; ++c) {
+            const ClusterF4 mid = out.bounds[2u * c], half = out.bounds[2u * c + 1u];
+            const float m[3] = {mid.x, mid.y, mid.z}, h[3] = {half.x, half.y, half.z};
+            const uint32_t ia = out.flat_axis == 0u ? 1u : 0u, ib = out.flat_axis == 2u ? 1u : 2u;
+            out.bounds.push_back(ClusterF4{m[ia], m[ib], h[ia], h[ib]});
         }
     }
 }

@@ -35,6 +35,8 @@ struct RtContext {
     uint32_t* d_cidx = nullptr;
     float4* d_cbounds = nullptr;
     uint32_t n_clusters = 0, n_super = 0, n_large = 0, n_large_slots = 0, n_cslots = 0;
+    uint32_t flat_axis = 3;       // (rtiow_clusters.cpp: the axis all cluster boxes share an interval along; 3: none)
+    float flat_mid = 0, flat_half = 0;
     float cluster_center[3] = {0, 0, 0};
     float cluster_diag = 0, cluster_rmax2 = 0;
     uint32_t last_kernel = 0;     // variant the last PATH render launched

@@ -68,7 +68,11 @@ struct PathArgs {
     const float4* cslots;        // clustered: n_cslots x {cx,cy,cz,r*r}; padding never hit.  The first
                                  // n_large_slots hold the large spheres, then kClusterStride per cluster
     const uint32_t* cidx;        // clustered: original index of every slot (0xFFFFFFFF = padding)
-    const float4* cbounds;       // clustered: n_clusters x {box centre, box half extent}
+    const float4* cbounds;       // clustered: n_clusters x {box centre, box half extent}, then the super-clusters' boxes; then
+                                 // (flat_axis < 3) one float4 per box without the flat axis: {mid a, mid b, half a, half b}
+    const float4* cbounds2;      // (flat_axis < 3) the boxes without the flat axis: n_clusters, then the super-clusters'
+    uint32_t flat_axis;          // 0..2: every box spans the interval flat_mid +- flat_half along this axis (a union: conservative); 3: none
+    float flat_mid, flat_half;
     uint32_t n_clusters;         // multiple of kSuperSize
     uint32_t n_super;            // super-clusters (0: none); their boxes follow the clusters' in cbounds
     uint32_t n_large;            // large spheres (tested exactly by every ray)
@@ -115,7 +119,10 @@ struct ClusterF4 {
 struct ClusterScene {  // host-side result of build_clusters
     std::vector<ClusterF4> slots;
     std::vector<uint32_t> idx;
-    std::vector<ClusterF4> bounds;  // two per cluster: centre, half extent; then two per super-cluster
+    std::vector<ClusterF4> bounds;  // two per cluster: centre, half extent; then two per super-cluster; then (flat_axis < 3)
+                                    // one per cluster and super-cluster: the box without its flat axis {mid a, mid b, half a, half b}
+    uint32_t flat_axis = 3;         // axis along which all cluster boxes span (nearly) one interval; 3: none
+    float flat_mid = 0, flat_half = 0;  // that interval (the union of the boxes')
     uint32_t n_clusters = 0, n_super = 0;
     uint32_t n_large = 0, n_large_slots = 0;
     float center[3] = {0, 0, 0};  // of the clustered spheres

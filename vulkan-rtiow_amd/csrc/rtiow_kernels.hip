@@ -676,7 +676,7 @@ struct PersistArgs {
     float abs_margin;      // absolute slack of the cone test: 2^-16 of the scene's coordinate range
 };
 using PersistentKernelFn = void (*)(PathArgs, PersistArgs);
-PersistentKernelFn small_clustered_kernel();  // path_persistent_kernel<true, true>, from the second compilation of this file
+PersistentKernelFn small_clustered_kernel(bool flat);  // path_persistent_kernel<true, true, flat>, from the second compilation of this file
 namespace {
 
 DI void examine_candidate(const float4* lds, uint32_t j, uint32_t n, const Path& p, float& best,
@@ -938,6 +938,36 @@ HDI float slab_gap(const float4& mid, const float4& half, float ix, float iy, fl
     return tf - tn;
 }
 
+// The same with the flat axis taken out (rtiow_clusters.cpp): every cluster box spans the common interval flat_mid +-
+// flat_half along one axis, so the ray's entry into and exit from THAT slab (tn_f >= 0, tf_f) are worked out once per
+// ray, and a box is one float4 {mid a, mid b, half a, half b} of the other two axes: 6 fma, v_max3, v_min3, one
+// subtraction -- 9 instructions and one 16-byte LDS read per ray and box instead of 13 and two.
+HDI float slab_gap_flat(const float4& box, float ia, float ib, float oa, float ob, float tn_f, float tf_f) {
+    const float tca = fma_(box.x, ia, oa);
+    const float tcb = fma_(box.y, ib, ob);
+    const float ja = __builtin_fabsf(ia), jb = __builtin_fabsf(ib);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(fma_(-box.z, ja, tca), fma_(-box.w, jb, tcb)), tn_f);
+    const float tf = __builtin_fminf(__builtin_fminf(fma_(box.z, ja, tca), fma_(box.w, jb, tcb)), tf_f);
+    return tf - tn;
+}
+// a ray's part in it: the two remaining axes' reciprocal direction and -o/d, and the ray's interval in the common slab
+struct FlatRay {
+    float ia, ib, oa, ob, tn_f, tf_f;
+};
+DI FlatRay flat_ray(const PathArgs& a, float ix, float iy, float iz, float ax, float ay, float az) {
+    const uint32_t fa = a.flat_axis;  // (wave-uniform)
+    const float i_f = fa == 0u ? ix : (fa == 1u ? iy : iz), o_f = fa == 0u ? ax : (fa == 1u ? ay : az);
+    FlatRay f;
+    f.ia = fa == 0u ? iy : ix;
+    f.oa = fa == 0u ? ay : ax;
+    f.ib = fa == 2u ? iy : iz;
+    f.ob = fa == 2u ? ay : az;
+    const float tc = fma_(a.flat_mid, i_f, o_f), jf = __builtin_fabsf(i_f);
+    f.tn_f = __builtin_fmaxf(fma_(-a.flat_half, jf, tc), 0.0f);
+    f.tf_f = fma_(a.flat_half, jf, tc);
+    return f;
+}
+
 // the ray of path slot (item bit 6) of lane (item bits 0-5), for every lane's own item
 template <int R>
 DI void fetch_item_ray(const Slot (&sl)[R], uint32_t item, float& ox, float& oy, float& oz, float& dx, float& dy,
@@ -1003,8 +1033,9 @@ DI void walk_clusters(const float4* slots, const uint32_t* idx_map, const PathAr
 // SUPER: the instantiation can meet super-clusters (a.n_super != 0).  Small scenes -- those whose shading records sit
 // in LDS, at most ~580 spheres -- never have them (kSuperFrom clusters = 1536 spheres): their kernel is compiled
 // without that level, which is a third of this function and would otherwise weigh on its register allocation.
-template <int R, bool SUPER>
-DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const float4* bounds, const PathArgs& a,
+// FLAT: the boxes are tested without their flat axis (slab_gap_flat; `bounds2`: one float4 per box).
+template <int R, bool SUPER, bool FLAT>
+DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const float4* bounds, const float4* bounds2, const PathArgs& a,
                         uint16_t* items, unsigned long long* results,
                         Slot (&sl)[R], float (&best)[R], int (&best_i)[R], uint32_t (&best_o)[R],
                         uint32_t& n_tests, uint32_t& dbg_slow_trips, uint32_t& dbg_cands,
@@ -1026,7 +1057,21 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
         az[r] = -p.o.z * iz[r];
         const float qx = p.o.x - a.ccenter[0], qy = p.o.y - a.ccenter[1], qz = p.o.z - a.ccenter[2];
         outside[r] = !(fma_(qz, qz, fma_(qy, qy, qx * qx)) <= a.crmax2);
+        if (FLAT) {  // (ix, iz, ax, az become the two box axes; iy, ay the ray's interval in the common slab)
+            const FlatRay f = flat_ray(a, ix[r], iy[r], iz[r], ax[r], ay[r], az[r]);
+            ix[r] = f.ia;
+            iz[r] = f.ib;
+            ax[r] = f.oa;
+            az[r] = f.ob;
+            iy[r] = f.tn_f;
+            ay[r] = f.tf_f;
+        }
     }
+    // one box against the ray of slot r: sign bit set = not reached
+    auto gap_of = [&](const float4& mid, const float4& half, int r) {
+        return FLAT ? slab_gap_flat(mid, ix[r], iz[r], ax[r], az[r], iy[r], ay[r])
+                    : slab_gap(mid, half, ix[r], iy[r], iz[r], ax[r], ay[r], az[r]);
+    };
     // ---- phase 0: the large spheres, every ray, exact ----
     // A few of them (the cover scene has four: the ground and the three big balls): straight through the exact test,
     // in lock-step, no candidate stage.  Nearly every ray is a candidate for the ground anyway (its line meets the huge
@@ -1121,17 +1166,22 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
                 float4 mid[4], half[4];
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u) {
-                    mid[u] = bounds[2u * (g0 + j + u)];
-                    half[u] = bounds[2u * (g0 + j + u) + 1u];  // LDS broadcast
+                    if (FLAT) {
+                        mid[u] = half[u] = bounds2[g0 + j + u];  // LDS broadcast: one read per box
+                    } else {
+                        mid[u] = bounds[2u * (g0 + j + u)];
+                        half[u] = bounds[2u * (g0 + j + u) + 1u];  // LDS broadcast
+                    }
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u) {
 #pragma unroll
                     for (int r = 0; r < R; ++r)
-                        miss[r] = __builtin_amdgcn_alignbit(
-                            miss[r], __float_as_uint(slab_gap(mid[u], half[u], ix[r], iy[r], iz[r], ax[r], ay[r], az[r])), 31);
-                    keep_b128(mid[u]);   // (after the use: the asm waits for the read)
-                    keep_b128(half[u]);
+                        miss[r] = __builtin_amdgcn_alignbit(miss[r], __float_as_uint(gap_of(mid[u], half[u], r)), 31);
+                    if (!FLAT) {
+                        keep_b128(mid[u]);   // (after the use: the asm waits for the read)
+                        keep_b128(half[u]);
+                    }
                 }
             }
             [[maybe_unused]] const unsigned long long ts0 = DBG_STAMP();
@@ -1173,6 +1223,7 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
         static_assert(64u * kSuperSize <= kItemCap, "one round of (ray, super-cluster) items must fit the cluster list");
         static_assert(32u * kSuperSize <= 512u, "cluster-in-group index must fit the 9 bits above lane and slot");
         const float4* sbounds = bounds + 2u * a.n_clusters;
+        [[maybe_unused]] const float4* sbounds2 = bounds2 + a.n_clusters;
         uint16_t* sitems = items + kItemCap;
         for (uint32_t s0 = 0; s0 < a.n_super; s0 += 32u) {
             uint32_t miss[R];
@@ -1184,25 +1235,29 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
                 float4 mid[4], half[4];
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u) {
-                    mid[u] = sbounds[2u * (s0 + j + u)];
-                    half[u] = sbounds[2u * (s0 + j + u) + 1u];  // LDS broadcast
+                    if (FLAT) {
+                        mid[u] = half[u] = sbounds2[s0 + j + u];  // LDS broadcast: one read per box
+                    } else {
+                        mid[u] = sbounds[2u * (s0 + j + u)];
+                        half[u] = sbounds[2u * (s0 + j + u) + 1u];  // LDS broadcast
+                    }
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u) {
 #pragma unroll
                     for (int r = 0; r < R; ++r)
-                        miss[r] = __builtin_amdgcn_alignbit(
-                            miss[r], __float_as_uint(slab_gap(mid[u], half[u], ix[r], iy[r], iz[r], ax[r], ay[r], az[r])), 31);
-                    keep_b128(mid[u]);
-                    keep_b128(half[u]);
+                        miss[r] = __builtin_amdgcn_alignbit(miss[r], __float_as_uint(gap_of(mid[u], half[u], r)), 31);
+                    if (!FLAT) {
+                        keep_b128(mid[u]);
+                        keep_b128(half[u]);
+                    }
                 }
             }
             for (; j < jn; ++j) {
-                const float4 mid = sbounds[2u * (s0 + j)], half = sbounds[2u * (s0 + j) + 1u];  // LDS broadcast
+                const float4 mid = FLAT ? sbounds2[s0 + j] : sbounds[2u * (s0 + j)];  // LDS broadcast
+                const float4 half = FLAT ? mid : sbounds[2u * (s0 + j) + 1u];
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    miss[r] = __builtin_amdgcn_alignbit(
-                        miss[r], __float_as_uint(slab_gap(mid, half, ix[r], iy[r], iz[r], ax[r], ay[r], az[r])), 31);
+                for (int r = 0; r < R; ++r) miss[r] = __builtin_amdgcn_alignbit(miss[r], __float_as_uint(gap_of(mid, half, r)), 31);
             }
             [[maybe_unused]] const unsigned long long ts0 = DBG_STAMP();
             uint32_t sm[R];
@@ -1254,11 +1309,18 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
                     const float qx = ox - a.ccenter[0], qy = oy - a.ccenter[1], qz = oz - a.ccenter[2];
                     const bool out = !(fma_(qz, qz, fma_(qy, qy, qx * qx)) <= a.crmax2);
                     const uint32_t first = (s0 + (item >> 7)) * kSuperSize;
+                    [[maybe_unused]] FlatRay f{};
+                    if (FLAT) f = flat_ray(a, jx, jy, jz, bx, by, bz);
 #pragma unroll
                     for (uint32_t j = 0; j < kSuperSize; ++j) {
                         const uint32_t k = (j + lane) & (kSuperSize - 1u);  // lane-rotated: spreads the LDS banks
-                        const float4 mid = bounds[2u * (first + k)], half = bounds[2u * (first + k) + 1u];
-                        const bool reach = !__builtin_signbit(slab_gap(mid, half, jx, jy, jz, bx, by, bz));
+                        bool reach;
+                        if (FLAT) {
+                            reach = !__builtin_signbit(slab_gap_flat(bounds2[first + k], f.ia, f.ib, f.oa, f.ob, f.tn_f, f.tf_f));
+                        } else {
+                            const float4 mid = bounds[2u * (first + k)], half = bounds[2u * (first + k) + 1u];
+                            reach = !__builtin_signbit(slab_gap(mid, half, jx, jy, jz, bx, by, bz));
+                        }
                         hit8 |= (reach ? 1u : 0u) << k;
                     }
                     if (out) hit8 = (1u << kSuperSize) - 1u;
@@ -1780,9 +1842,12 @@ constexpr int kAccelMaxThreads = RTIOW_ACCEL_MAX_THREADS;
 #ifndef RTIOW_TAIL_LOOP
 #define RTIOW_TAIL_LOOP 1  // (-DRTIOW_TAIL_LOOP=0: A/B only)
 #endif
-template <bool SHADE_LDS, bool ACCEL>
+// FLAT (clustered kernels): the scene's cluster boxes share one interval along a.flat_axis, and the lock-step box tests
+// leave that axis out (slab_gap_flat).
+template <bool SHADE_LDS, bool ACCEL, bool FLAT = false>
 __global__ __launch_bounds__(ACCEL ? (SHADE_LDS ? RTIOW_SMALL_MAX_THREADS : kAccelMaxThreads) : 1024) __attribute__((amdgpu_waves_per_eu(ACCEL && !SHADE_LDS ? 3 : 1)))
 void path_persistent_kernel(PathArgs a, PersistArgs g) {
+    static_assert(ACCEL || !FLAT, "only the clustered list has boxes");
     // LDS: sphere list [g.n_pad float4] — the flat list, or (ACCEL) the clustered list's slots, then
     // (ACCEL) the slots' original indices [g.n_pad u32] and the boxes [2 (a.n_clusters + a.n_super) float4];
     // then (SHADE_LDS) two float4 of shading record per sphere; then the accumulator entries of every
@@ -1797,7 +1862,9 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     if (threadIdx.x == 3u) wg_left = 0u;
     uint32_t* lds_cidx = reinterpret_cast<uint32_t*>(lds_spheres + g.n_pad);
     float4* lds_cbounds = reinterpret_cast<float4*>(lds_cidx + (ACCEL ? g.n_pad : 0u));
-    float4* lds_shade = lds_cbounds + (ACCEL ? 2u * (a.n_clusters + a.n_super) : 0u);
+    // (boxes: centre + half extent each; FLAT: then once more without the flat axis, one float4 each)
+    float4* lds_shade = lds_cbounds + (ACCEL ? (FLAT ? 3u : 2u) * (a.n_clusters + a.n_super) : 0u);
+    [[maybe_unused]] const float4* lds_cbounds2 = lds_cbounds + 2u * (a.n_clusters + a.n_super);
     unsigned long long* lds_acc = reinterpret_cast<unsigned long long*>(lds_shade + (SHADE_LDS ? 2u * a.n : 0u));
     const uint32_t waves_in_group = blockDim.x / 64u;
     const uint32_t wave_in_group = threadIdx.x / 64u;
@@ -1820,6 +1887,8 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             lds_cidx[i] = a.cidx[i];
         }
         for (uint32_t i = threadIdx.x; i < 2u * (a.n_clusters + a.n_super); i += blockDim.x) lds_cbounds[i] = a.cbounds[i];
+        if (FLAT)  // (a list of their own in HBM: launch_path may have dropped the super level, whose full boxes lie in between)
+            for (uint32_t i = threadIdx.x; i < a.n_clusters + a.n_super; i += blockDim.x) lds_cbounds[2u * (a.n_clusters + a.n_super) + i] = a.cbounds2[i];
     } else {
         stage_spheres(a, lds_spheres, g.n_pad);
     }
@@ -2361,7 +2430,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 if (sl[r].active) n_tests += a.n;
             DBG_ADD(dbg_sparse, lane == 0u ? 1u : 0u);
         } else if (ACCEL) {
-            trace_clustered<kSlots, !SHADE_LDS>(lds_spheres, lds_cidx, lds_cbounds, a, lds_items, lds_results, sl, best, best_i, best_o, n_tests,
+            trace_clustered<kSlots, !SHADE_LDS, FLAT>(lds_spheres, lds_cidx, lds_cbounds, lds_cbounds2, a, lds_items, lds_results, sl, best, best_i, best_o, n_tests,
                                     dbg_slow_trips, dbg_cands, dbg_t_slow);
         } else {
             trace_slots<kSlots>(lds_spheres, g.n_pad, a.n, sl, best, best_i, dbg_slow_trips, dbg_cands, dbg_t_slow);
@@ -2635,7 +2704,9 @@ __global__ __launch_bounds__(1024) void order_chunks_kernel(unsigned long long* 
 // 8.64 -> 8.40 ms, one eighth of it 1.46 -> 1.41 (interleaved A/B, tools/ab_bench.py).  The large-scene variant spills
 // under that scheduler (C5 1.16 -> 1.22 s) and the flat-list kernels lose 1 % to it, so they stay with the default.
 #ifdef RTIOW_TU_SMALL_CLUSTERED
-PersistentKernelFn small_clustered_kernel() { return path_persistent_kernel<true, true>; }
+PersistentKernelFn small_clustered_kernel(bool flat) {
+    return flat ? path_persistent_kernel<true, true, true> : path_persistent_kernel<true, true, false>;
+}
 #else
 
 hipError_t launch_order_chunks(unsigned long long* cost, uint32_t* order, uint32_t n_chunks, uint32_t spp, hipStream_t stream) {
@@ -2750,8 +2821,26 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     constexpr size_t kLdsPerCu = 160u * 1024u - 256u;  // (the kernel's static __shared__ words come on top of the dynamic part)
     // The clustered list must fit the LDS beside four waves' buffers.  The very largest scenes give up
     // the super-cluster level first (its boxes and second work list), then fall back to the flat list.
+    // the flat axis (rtiow_clusters.cpp): RTIOW_DEBUG_FLAT=0 tests the whole boxes all the same (A/B and parity tests;
+    // RTIOW_DEBUG_FLAT=1, read by rtSetScene, makes every scene flat along its best axis)
+    if (!accel || (getenv("RTIOW_DEBUG_FLAT") && atoi(getenv("RTIOW_DEBUG_FLAT")) == 0)) a.flat_axis = 3u;
+    // ... and only where its 16 bytes per box do not cost a wave: a scene whose lists fill the LDS (C5: 92 KB of them beside
+    // twelve waves' buffers) would run eight waves per CU instead of twelve with them -- 26.2 against 21.2 ms for a
+    // 16-spp C5 frame -- and keeps the whole boxes
+    {
+        constexpr size_t kLds = 160u * 1024u - 256u;
+        const size_t shade = static_cast<size_t>(a.n) * sizeof(ShadeRec);
+        const size_t lists = static_cast<size_t>(a.n_cslots) * 20u + static_cast<size_t>(a.n_clusters + a.n_super) * 32u;
+        const size_t lists_flat = lists + static_cast<size_t>(a.n_clusters + a.n_super) * 16u;
+        const size_t wave = kWaveAccBytes + kWaveLineBytes + wave_item_bytes(a.n_super != 0u) + kPassKeep * kPassRecBytes;
+        const bool roomy = lists_flat + shade <= 28u * 1024u ||                              // a small scene stays one: three groups of 256
+                           (lists + shade > 28u * 1024u && lists_flat + 12u * wave <= kLds);  // a large one keeps its twelve waves
+        if (!roomy) a.flat_axis = 3u;
+    }
+    const bool flat = a.flat_axis < 3u;
+    const uint32_t box_bytes = flat ? 48u : 32u;
     auto clustered_fits = [&](uint32_t n_super) {
-        return static_cast<size_t>(a.n_cslots) * 20u + static_cast<size_t>(a.n_clusters + n_super) * 32u +
+        return static_cast<size_t>(a.n_cslots) * 20u + static_cast<size_t>(a.n_clusters + n_super) * box_bytes +
                    4u * (kWaveAccBytes + kWaveLineBytes + wave_item_bytes(n_super != 0u)) <= kLdsPerCu;  // at least one 256-thread group
     };
     if (accel && !clustered_fits(a.n_super)) a.n_super = 0u;
@@ -2776,7 +2865,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // 2 KiB of pixel accumulator entries and 0.5 KiB of line buffers per wave (clustered: + 2-3 KiB of work lists
     // and result keys).
     const size_t lds_geo = static_cast<size_t>(g.n_pad) * sizeof(float4) +
-                           (accel ? static_cast<size_t>(g.n_pad) * 4u + static_cast<size_t>(a.n_clusters + a.n_super) * 32u : 0u);
+                           (accel ? static_cast<size_t>(g.n_pad) * 4u + static_cast<size_t>(a.n_clusters + a.n_super) * box_bytes : 0u);
     const bool shade_lds = lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 28u * 1024u &&
                            !getenv("RTIOW_DEBUG_NO_SHADE_LDS");  // (tuning only)
     const size_t lds_scene = lds_geo + (shade_lds ? static_cast<size_t>(a.n) * sizeof(ShadeRec) : 0u);
@@ -2786,7 +2875,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // make no more paths than there are idle slots, and the records sit in the two-level work-list area alone
     auto wave_bytes = [&](uint32_t keep) { return kWaveAccBytes + kWaveLineBytes + (accel ? item_bytes + keep * kPassRecBytes : 0u); };
     void (*kernel_fn)(PathArgs, PersistArgs) =
-        accel ? (shade_lds ? small_clustered_kernel() : path_persistent_kernel<false, true>)
+        accel ? (shade_lds ? small_clustered_kernel(flat) : (flat ? path_persistent_kernel<false, true, true> : path_persistent_kernel<false, true, false>))
               : (shade_lds ? path_persistent_kernel<true, false> : path_persistent_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsPerCu));
