@@ -968,6 +968,23 @@ DI FlatRay flat_ray(const PathArgs& a, float ix, float iy, float iz, float ax, f
     return f;
 }
 
+// Box number i of the clustered list (clusters first, then super-clusters) as centre + half extent.  !FLAT: as stored.
+// FLAT: the list holds the boxes without their flat axis only -- 16 bytes a box instead of 32 -- and the whole box is
+// made up with the common interval, i.e. a box that CONTAINS the real one: fine for every test that only culls (the
+// cone tests of the primary pass, the slab tests of the sparse trace).
+template <bool FLAT>
+DI void load_box(const float4* bounds, const PathArgs& a, uint32_t i, float4& mid, float4& half) {
+    if (!FLAT) {
+        mid = bounds[2u * i];
+        half = bounds[2u * i + 1u];
+        return;
+    }
+    const float4 b = bounds[i];
+    const uint32_t fa = a.flat_axis;  // (wave-uniform)
+    mid = make_float4(fa == 0u ? a.flat_mid : b.x, fa == 0u ? b.x : (fa == 1u ? a.flat_mid : b.y), fa == 2u ? a.flat_mid : b.y, 0.0f);
+    half = make_float4(fa == 0u ? a.flat_half : b.z, fa == 0u ? b.z : (fa == 1u ? a.flat_half : b.w), fa == 2u ? a.flat_half : b.w, 0.0f);
+}
+
 // the ray of path slot (item bit 6) of lane (item bits 0-5), for every lane's own item
 template <int R>
 DI void fetch_item_ray(const Slot (&sl)[R], uint32_t item, float& ox, float& oy, float& oz, float& dx, float& dy,
@@ -1033,9 +1050,9 @@ DI void walk_clusters(const float4* slots, const uint32_t* idx_map, const PathAr
 // SUPER: the instantiation can meet super-clusters (a.n_super != 0).  Small scenes -- those whose shading records sit
 // in LDS, at most ~580 spheres -- never have them (kSuperFrom clusters = 1536 spheres): their kernel is compiled
 // without that level, which is a third of this function and would otherwise weigh on its register allocation.
-// FLAT: the boxes are tested without their flat axis (slab_gap_flat; `bounds2`: one float4 per box).
+// FLAT: the boxes are tested without their flat axis (slab_gap_flat; `bounds` then holds one float4 per box).
 template <int R, bool SUPER, bool FLAT>
-DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const float4* bounds, const float4* bounds2, const PathArgs& a,
+DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const float4* bounds, const PathArgs& a,
                         uint16_t* items, unsigned long long* results,
                         Slot (&sl)[R], float (&best)[R], int (&best_i)[R], uint32_t (&best_o)[R],
                         uint32_t& n_tests, uint32_t& dbg_slow_trips, uint32_t& dbg_cands,
@@ -1167,7 +1184,7 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u) {
                     if (FLAT) {
-                        mid[u] = half[u] = bounds2[g0 + j + u];  // LDS broadcast: one read per box
+                        mid[u] = half[u] = bounds[g0 + j + u];  // LDS broadcast: one read per box
                     } else {
                         mid[u] = bounds[2u * (g0 + j + u)];
                         half[u] = bounds[2u * (g0 + j + u) + 1u];  // LDS broadcast
@@ -1222,8 +1239,7 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
         // cluster boxes of the (ray, super-cluster) pairs that pass, one pair per lane, then the members ----
         static_assert(64u * kSuperSize <= kItemCap, "one round of (ray, super-cluster) items must fit the cluster list");
         static_assert(32u * kSuperSize <= 512u, "cluster-in-group index must fit the 9 bits above lane and slot");
-        const float4* sbounds = bounds + 2u * a.n_clusters;
-        [[maybe_unused]] const float4* sbounds2 = bounds2 + a.n_clusters;
+        const float4* sbounds = bounds + (FLAT ? 1u : 2u) * a.n_clusters;
         uint16_t* sitems = items + kItemCap;
         for (uint32_t s0 = 0; s0 < a.n_super; s0 += 32u) {
             uint32_t miss[R];
@@ -1236,7 +1252,7 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u) {
                     if (FLAT) {
-                        mid[u] = half[u] = sbounds2[s0 + j + u];  // LDS broadcast: one read per box
+                        mid[u] = half[u] = sbounds[s0 + j + u];  // LDS broadcast: one read per box
                     } else {
                         mid[u] = sbounds[2u * (s0 + j + u)];
                         half[u] = sbounds[2u * (s0 + j + u) + 1u];  // LDS broadcast
@@ -1254,7 +1270,7 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
                 }
             }
             for (; j < jn; ++j) {
-                const float4 mid = FLAT ? sbounds2[s0 + j] : sbounds[2u * (s0 + j)];  // LDS broadcast
+                const float4 mid = FLAT ? sbounds[s0 + j] : sbounds[2u * (s0 + j)];  // LDS broadcast
                 const float4 half = FLAT ? mid : sbounds[2u * (s0 + j) + 1u];
 #pragma unroll
                 for (int r = 0; r < R; ++r) miss[r] = __builtin_amdgcn_alignbit(miss[r], __float_as_uint(gap_of(mid, half, r)), 31);
@@ -1316,7 +1332,7 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
                         const uint32_t k = (j + lane) & (kSuperSize - 1u);  // lane-rotated: spreads the LDS banks
                         bool reach;
                         if (FLAT) {
-                            reach = !__builtin_signbit(slab_gap_flat(bounds2[first + k], f.ia, f.ib, f.oa, f.ob, f.tn_f, f.tf_f));
+                            reach = !__builtin_signbit(slab_gap_flat(bounds[first + k], f.ia, f.ib, f.oa, f.ob, f.tn_f, f.tf_f));
                         } else {
                             const float4 mid = bounds[2u * (first + k)], half = bounds[2u * (first + k) + 1u];
                             reach = !__builtin_signbit(slab_gap(mid, half, jx, jy, jz, bx, by, bz));
@@ -1403,7 +1419,7 @@ DI void sparse_members(const float4* slots, const uint32_t* idx_map, const PathA
     }
 }
 
-template <int R, bool SUPER>
+template <int R, bool SUPER, bool FLAT>
 DI void trace_sparse_parallel(const float4* slots, const uint32_t* idx_map, const float4* bounds, const PathArgs& a,
                               uint16_t* items, unsigned long long* results, Slot (&sl)[R], float (&best)[R],
                               int (&best_i)[R], uint32_t (&best_o)[R], uint32_t& n_tests) {
@@ -1429,7 +1445,7 @@ DI void trace_sparse_parallel(const float4* slots, const uint32_t* idx_map, cons
     if (lane < n_live) keys[lane] = ~0ull;
     // (a wave's LDS operations are performed in order: rays and keys are in place for what follows)
     const bool two_level = SUPER && a.n_super != 0u;
-    const float4* top = two_level ? bounds + 2u * a.n_clusters : bounds;
+    const uint32_t top = two_level ? a.n_clusters : 0u;  // number of the first box of the top level
     const uint32_t n_top = two_level ? a.n_super : a.n_clusters;
     uint16_t* top_items = two_level ? items + kItemCap : items;
     uint32_t pending = 0u;   // items in top_items
@@ -1454,7 +1470,8 @@ DI void trace_sparse_parallel(const float4* slots, const uint32_t* idx_map, cons
                 const float ix = slab_rcp(ray.dx), iy = slab_rcp(ray.dy), iz = slab_rcp(ray.dz);
                 const float qx = ray.ox - a.ccenter[0], qy = ray.oy - a.ccenter[1], qz = ray.oz - a.ccenter[2];
                 const bool outside = !(fma_(qz, qz, fma_(qy, qy, qx * qx)) <= a.crmax2);
-                const float4 mid = bounds[2u * c], half = bounds[2u * c + 1u];
+                float4 mid, half;
+                load_box<FLAT>(bounds, a, c, mid, half);
                 reach = outside || !__builtin_signbit(slab_gap(mid, half, ix, iy, iz, -ray.ox * ix, -ray.oy * iy, -ray.oz * iz));
                 ++n_tests;
                 out_item = p | (c << 5);
@@ -1502,7 +1519,8 @@ DI void trace_sparse_parallel(const float4* slots, const uint32_t* idx_map, cons
         const uint32_t b = base + j0;
         bool reach = false;
         if (mine && b < n_top) {
-            const float4 mid = top[2u * b], half = top[2u * b + 1u];
+            float4 mid, half;
+            load_box<FLAT>(bounds, a, top + b, mid, half);
             reach = outside || !__builtin_signbit(slab_gap(mid, half, ix, iy, iz, ax, ay, az));
             ++n_tests;
         }
@@ -1651,13 +1669,15 @@ HDI bool cone_reaches(const PathArgs& a, const PersistArgs& g, const ConeAxis& c
 
 // One 32-bit mask, wave-uniform: bit k set = box first + k (of `boxes`, n of them) can be reached by a ray of one
 // of the spans.  Lanes 0-31 look at one span and lanes 32-63 at the next: two spans per evaluation.
-DI uint32_t cone_mask(const PathArgs& a, const PersistArgs& g, const float4* boxes, uint32_t n, uint32_t first,
+template <bool FLAT>
+DI uint32_t cone_mask(const PathArgs& a, const PersistArgs& g, const float4* bounds, uint32_t base, uint32_t n, uint32_t first,
                       const ConeAxis& c0, const uint32_t (&span_lo)[kPassSpans], const uint32_t (&span_hi)[kPassSpans],
                       uint32_t n_spans) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t b = first + (lane & 31u);
     const bool in = b < n;
-    const float4 mid = boxes[2u * (in ? b : 0u)], half = boxes[2u * (in ? b : 0u) + 1u];
+    float4 mid, half;
+    load_box<FLAT>(bounds, a, base + (in ? b : 0u), mid, half);  // (`base`: number of the level's first box in the list)
     bool reach = in && cone_reaches(a, g, c0, mid, half);
     const unsigned long long m = __ballot(reach);
     return static_cast<uint32_t>(m) | static_cast<uint32_t>(m >> 32);
@@ -1702,7 +1722,7 @@ DI void exact_keyed_lockstep(const float4* slots, const uint32_t* idx_map, uint3
 // both wave-uniform: the cluster boxes the spans' cones reach, then -- lane by lane, one sphere each -- the members of
 // those clusters (and the large spheres) the cones reach; what is left, typically the ground and a sphere or two, takes
 // the exact test in lock-step.  Same test, same key, same minimum as trace_clustered for every sphere that can be hit.
-template <bool SUPER>
+template <bool SUPER, bool FLAT>
 DI void primary_trace(const float4* slots, const uint32_t* idx_map, const float4* bounds, const PathArgs& a,
                       const PersistArgs& g, const Path& p, bool active, const uint32_t (&span_lo)[kPassSpans],
                       const uint32_t (&span_hi)[kPassSpans], uint32_t n_spans, float& best, int& best_i,
@@ -1754,7 +1774,7 @@ DI void primary_trace(const float4* slots, const uint32_t* idx_map, const float4
         for (uint32_t g0 = 0; g0 < a.n_clusters; g0 += 32u) {
             uint32_t cm = 0xFFFFFFFFu;
             if (!use_all) {
-                cm = cone_mask(a, g, bounds, a.n_clusters, g0, c0, span_lo, span_hi, n_spans);
+                cm = cone_mask<FLAT>(a, g, bounds, 0u, a.n_clusters, g0, c0, span_lo, span_hi, n_spans);
                 n_tests += g0 + half < a.n_clusters ? 1u : 0u;
             }
             if (a.n_clusters - g0 < 32u) cm &= (1u << (a.n_clusters - g0)) - 1u;
@@ -1765,11 +1785,10 @@ DI void primary_trace(const float4* slots, const uint32_t* idx_map, const float4
             }
         }
     } else {
-        const float4* sbounds = bounds + 2u * a.n_clusters;
         for (uint32_t s0 = 0; s0 < a.n_super; s0 += 32u) {
             uint32_t sm = 0xFFFFFFFFu;
             if (!use_all) {
-                sm = cone_mask(a, g, sbounds, a.n_super, s0, c0, span_lo, span_hi, n_spans);
+                sm = cone_mask<FLAT>(a, g, bounds, a.n_clusters, a.n_super, s0, c0, span_lo, span_hi, n_spans);
                 n_tests += s0 + half < a.n_super ? 1u : 0u;
             }
             if (a.n_super - s0 < 32u) sm &= (1u << (a.n_super - s0)) - 1u;
@@ -1788,7 +1807,8 @@ DI void primary_trace(const float4* slots, const uint32_t* idx_map, const float4
                 const uint32_t c = (in ? my_sup : 0u) * kSuperSize + (lane & 7u);
                 bool reach = in;
                 if (!use_all) {
-                    const float4 mid = bounds[2u * c], hext = bounds[2u * c + 1u];
+                    float4 mid, hext;
+                    load_box<FLAT>(bounds, a, c, mid, hext);
                     reach = in && cone_reaches(a, g, c0, mid, hext);
                     n_tests += in ? 1u : 0u;
                 }
@@ -1862,9 +1882,8 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     if (threadIdx.x == 3u) wg_left = 0u;
     uint32_t* lds_cidx = reinterpret_cast<uint32_t*>(lds_spheres + g.n_pad);
     float4* lds_cbounds = reinterpret_cast<float4*>(lds_cidx + (ACCEL ? g.n_pad : 0u));
-    // (boxes: centre + half extent each; FLAT: then once more without the flat axis, one float4 each)
-    float4* lds_shade = lds_cbounds + (ACCEL ? (FLAT ? 3u : 2u) * (a.n_clusters + a.n_super) : 0u);
-    [[maybe_unused]] const float4* lds_cbounds2 = lds_cbounds + 2u * (a.n_clusters + a.n_super);
+    // (boxes: centre + half extent, two float4 each; FLAT: without the flat axis, one float4 each)
+    float4* lds_shade = lds_cbounds + (ACCEL ? (FLAT ? 1u : 2u) * (a.n_clusters + a.n_super) : 0u);
     unsigned long long* lds_acc = reinterpret_cast<unsigned long long*>(lds_shade + (SHADE_LDS ? 2u * a.n : 0u));
     const uint32_t waves_in_group = blockDim.x / 64u;
     const uint32_t wave_in_group = threadIdx.x / 64u;
@@ -1886,9 +1905,11 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             lds_spheres[i] = a.cslots[i];
             lds_cidx[i] = a.cidx[i];
         }
-        for (uint32_t i = threadIdx.x; i < 2u * (a.n_clusters + a.n_super); i += blockDim.x) lds_cbounds[i] = a.cbounds[i];
-        if (FLAT)  // (a list of their own in HBM: launch_path may have dropped the super level, whose full boxes lie in between)
-            for (uint32_t i = threadIdx.x; i < a.n_clusters + a.n_super; i += blockDim.x) lds_cbounds[2u * (a.n_clusters + a.n_super) + i] = a.cbounds2[i];
+        if (FLAT) {  // (a list of their own in HBM, clusters first: launch_path may have dropped the super level)
+            for (uint32_t i = threadIdx.x; i < a.n_clusters + a.n_super; i += blockDim.x) lds_cbounds[i] = a.cbounds2[i];
+        } else {
+            for (uint32_t i = threadIdx.x; i < 2u * (a.n_clusters + a.n_super); i += blockDim.x) lds_cbounds[i] = a.cbounds[i];
+        }
     } else {
         stage_spheres(a, lds_spheres, g.n_pad);
     }
@@ -2239,7 +2260,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     float pb;
                     int pb_i;
                     uint32_t pb_o;
-                    primary_trace<!SHADE_LDS>(lds_spheres, lds_cidx, lds_cbounds, a, g, ps.p, ps.active, span_lo, span_hi, n_spans,
+                    primary_trace<!SHADE_LDS, FLAT>(lds_spheres, lds_cidx, lds_cbounds, a, g, ps.p, ps.active, span_lo, span_hi, n_spans,
                                               pb, pb_i, pb_o, n_tests, dbg_pass[2]);
                     float4 pr0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pr1 = pr0;
                     if (!SHADE_LDS && ps.active && pb_i >= 0) {
@@ -2408,7 +2429,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             // few paths left: gather them in slot 0 (the shade and refill code below then runs once, not
             // once per slot), then trace them together
             compact_to_slot0(sl, reinterpret_cast<uint32_t*>(lds_results));
-            trace_sparse_parallel<kSlots, !SHADE_LDS>(lds_spheres, lds_cidx, lds_cbounds, a, lds_items, lds_results, sl, best, best_i,
+            trace_sparse_parallel<kSlots, !SHADE_LDS, FLAT>(lds_spheres, lds_cidx, lds_cbounds, a, lds_items, lds_results, sl, best, best_i,
                                           best_o, n_tests);
             TL_MARK(tl_sparse);
 #ifdef RTIOW_DEBUG_TIMELINE
@@ -2430,7 +2451,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 if (sl[r].active) n_tests += a.n;
             DBG_ADD(dbg_sparse, lane == 0u ? 1u : 0u);
         } else if (ACCEL) {
-            trace_clustered<kSlots, !SHADE_LDS, FLAT>(lds_spheres, lds_cidx, lds_cbounds, lds_cbounds2, a, lds_items, lds_results, sl, best, best_i, best_o, n_tests,
+            trace_clustered<kSlots, !SHADE_LDS, FLAT>(lds_spheres, lds_cidx, lds_cbounds, a, lds_items, lds_results, sl, best, best_i, best_o, n_tests,
                                     dbg_slow_trips, dbg_cands, dbg_t_slow);
         } else {
             trace_slots<kSlots>(lds_spheres, g.n_pad, a.n, sl, best, best_i, dbg_slow_trips, dbg_cands, dbg_t_slow);
@@ -2487,8 +2508,8 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 float best[kSlots];
                 int best_i[kSlots];
                 uint32_t best_o[kSlots];
-                trace_sparse_parallel<kSlots, !SHADE_LDS>(lds_spheres, lds_cidx, lds_cbounds, a, lds_items, lds_results, sl, best, best_i,
-                                                          best_o, n_tests);
+                trace_sparse_parallel<kSlots, !SHADE_LDS, FLAT>(lds_spheres, lds_cidx, lds_cbounds, a, lds_items, lds_results, sl, best, best_i,
+                                                                best_o, n_tests);
                 float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0;
                 if (!SHADE_LDS && sl[0].active && best_i[0] >= 0) {  // (large scenes: the hit's shading record from L2)
                     const float4* src = reinterpret_cast<const float4*>(a.shade + best_o[0]);
@@ -2824,21 +2845,8 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // the flat axis (rtiow_clusters.cpp): RTIOW_DEBUG_FLAT=0 tests the whole boxes all the same (A/B and parity tests;
     // RTIOW_DEBUG_FLAT=1, read by rtSetScene, makes every scene flat along its best axis)
     if (!accel || (getenv("RTIOW_DEBUG_FLAT") && atoi(getenv("RTIOW_DEBUG_FLAT")) == 0)) a.flat_axis = 3u;
-    // ... and only where its 16 bytes per box do not cost a wave: a scene whose lists fill the LDS (C5: 92 KB of them beside
-    // twelve waves' buffers) would run eight waves per CU instead of twelve with them -- 26.2 against 21.2 ms for a
-    // 16-spp C5 frame -- and keeps the whole boxes
-    {
-        constexpr size_t kLds = 160u * 1024u - 256u;
-        const size_t shade = static_cast<size_t>(a.n) * sizeof(ShadeRec);
-        const size_t lists = static_cast<size_t>(a.n_cslots) * 20u + static_cast<size_t>(a.n_clusters + a.n_super) * 32u;
-        const size_t lists_flat = lists + static_cast<size_t>(a.n_clusters + a.n_super) * 16u;
-        const size_t wave = kWaveAccBytes + kWaveLineBytes + wave_item_bytes(a.n_super != 0u) + kPassKeep * kPassRecBytes;
-        const bool roomy = lists_flat + shade <= 28u * 1024u ||                              // a small scene stays one: three groups of 256
-                           (lists + shade > 28u * 1024u && lists_flat + 12u * wave <= kLds);  // a large one keeps its twelve waves
-        if (!roomy) a.flat_axis = 3u;
-    }
     const bool flat = a.flat_axis < 3u;
-    const uint32_t box_bytes = flat ? 48u : 32u;
+    const uint32_t box_bytes = flat ? 16u : 32u;  // (LDS per box: without the flat axis one float4 instead of two)
     auto clustered_fits = [&](uint32_t n_super) {
         return static_cast<size_t>(a.n_cslots) * 20u + static_cast<size_t>(a.n_clusters + n_super) * box_bytes +
                    4u * (kWaveAccBytes + kWaveLineBytes + wave_item_bytes(n_super != 0u)) <= kLdsPerCu;  // at least one 256-thread group
