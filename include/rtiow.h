@@ -242,6 +242,18 @@ int rtConeSelfTestHost(const RtCamera* cam, uint32_t width, uint32_t height, uin
                        const float* range_center, float range_rmax, const RtSphere* spheres, uint32_t n_spheres,
                        const float* boxes, uint32_t n_boxes, uint8_t* sphere_reach, uint8_t* box_reach);
 
+/* CPU view of the two-level list rtSetScene builds for the clustered kernels (no GPU involved): for `spheres`, the boxes
+ * of the clusters and then of the super-clusters (six floats each: centre, half extent; at most box_cap of them are
+ * written), the original sphere index of every slot of the list (0xFFFFFFFF = padding; the first *n_large_slots slots
+ * hold the large spheres, then 16 per cluster), and the flat axis: *flat_axis = 0..2 when every cluster box spans
+ * (nearly) the interval flat_interval[0] +- flat_interval[1] along that axis -- the kernels then test the boxes without
+ * it -- or 3; flat_boxes receives four floats per box {centre a, centre b, half a, half b} of the other two axes.
+ * The tests: every sphere lies in its cluster's box, every cluster box in its super-cluster's, the common interval
+ * contains every box's.  No reference counterpart (the reference has one sphere, raytrace06.comp:39). */
+int rtClusterBuildHost(const RtSphere* spheres, uint32_t n_spheres, float range_diags, float* boxes, float* flat_boxes,
+                       uint32_t box_cap, uint32_t* n_clusters, uint32_t* n_super, uint32_t* slot_index, uint32_t slot_cap,
+                       uint32_t* n_slots, uint32_t* n_large_slots, uint32_t* flat_axis, float* flat_interval);
+
 /* CPU check of the chunk-order layout (cost-ordered dequeue): for a tile of n_chunks 32-pixel chunks, the words
  * rtRender allocates for the order (*words_out) and the highest word the kernels index (*max_slot_out), computed with
  * the functions both sides use; fails if two places of the sequence share a word.  No reference counterpart (the

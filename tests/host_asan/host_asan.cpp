@@ -103,7 +103,8 @@ int main(int argc, char** argv) {
             rtiow::build_clusters(rs.data(), count, range, cs);
             CHECK(cs.slots.size() == cs.idx.size());
             CHECK(cs.slots.size() == size_t(cs.n_large_slots) + size_t(cs.n_clusters) * rtiow::kClusterStride);
-            CHECK(cs.bounds.size() == 2u * (size_t(cs.n_clusters) + cs.n_super));
+            // (whole boxes: two entries each; then, in a flat scene, the boxes without the flat axis: one each)
+            CHECK(cs.bounds.size() == (cs.flat_axis < 3u ? 3u : 2u) * (size_t(cs.n_clusters) + cs.n_super));
             CHECK(cs.n_clusters % rtiow::kSuperSize == 0);
             std::vector<int> seen(count, 0);
             for (size_t k = 0; k < cs.idx.size(); ++k) {

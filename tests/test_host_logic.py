@@ -32,6 +32,55 @@ def test_chunk_order_fits_its_allocation():
         assert words == 8 * ((n + 7) // 8)
 
 
+@pytest.mark.parametrize("kind", ["cover", "cover4096", "layer_x", "cube", "tiny"])
+def test_cluster_build_boxes_contain_their_spheres_and_the_flat_interval_contains_the_boxes(kind):
+    """rtSetScene's two-level list on the CPU (rtClusterBuildHost runs build_clusters itself): every sphere sits in exactly one
+    slot; a small sphere lies inside its cluster's box and the cluster's box inside its super-cluster's; and when the scene
+    is flat along an axis -- the cover scenes are, along y -- the common interval contains every box's own interval and the
+    flat boxes are the whole boxes with that axis left out.  (Boxes only cull: containment is all correctness needs.)"""
+    rng = np.random.default_rng(5)
+    if kind in ("cover", "cover4096"):
+        sph, _ = V.make_cover_scene(1, 11 if kind == "cover" else 32)
+    else:
+        n = {"layer_x": 700, "cube": 900, "tiny": 5}[kind]
+        sph = np.zeros(n, V.SPHERE_DTYPE)
+        pos = rng.uniform(-3, 3, (n, 3))
+        if kind == "layer_x":
+            pos[:, 0] = rng.uniform(-0.01, 0.01, n)
+        sph["cx"], sph["cy"], sph["cz"] = pos[:, 0], pos[:, 1], pos[:, 2]
+        sph["radius"] = rng.uniform(0.05, 0.06, n) * rng.choice([1.0, -1.0], n)
+    b = V.cluster_build_host(sph)
+    idx = b["slot_index"]
+    real = idx[idx != 0xFFFFFFFF]
+    assert sorted(real.tolist()) == list(range(len(sph)))              # every sphere once
+    assert len(idx) == b["n_large_slots"] + 16 * b["n_clusters"]
+    c = np.stack([sph["cx"], sph["cy"], sph["cz"]], 1).astype(np.float64)
+    r = np.abs(sph["radius"]).astype(np.float64)
+    boxes = b["boxes"].astype(np.float64)
+    lo, hi = boxes[:, :3] - boxes[:, 3:], boxes[:, :3] + boxes[:, 3:]
+    for k in range(b["n_clusters"]):
+        members = idx[b["n_large_slots"] + 16 * k: b["n_large_slots"] + 16 * (k + 1)]
+        members = members[members != 0xFFFFFFFF]
+        for m in members:
+            assert (c[m] - r[m] >= lo[k]).all() and (c[m] + r[m] <= hi[k]).all(), (kind, k, m)
+        if b["n_super"] and len(members):
+            s_ = b["n_clusters"] + k // 8
+            assert (lo[k] >= lo[s_]).all() and (hi[k] <= hi[s_]).all(), (kind, k)
+    expect_axis = {"cover": 1, "cover4096": 1, "layer_x": 0, "cube": 3, "tiny": None}[kind]
+    if expect_axis is not None:
+        assert b["flat_axis"] == expect_axis, (kind, b["flat_axis"])
+    if b["flat_axis"] < 3:
+        fa = b["flat_axis"]
+        mid, half = b["flat_interval"]
+        occupied = [k for k in range(b["n_clusters"] + b["n_super"]) if boxes[k, 3:].max() > 0]   # (padding boxes are points far away)
+        assert all(lo[k, fa] >= mid - half and hi[k, fa] <= mid + half for k in occupied), kind
+        others = [ax for ax in range(3) if ax != fa]
+        want = np.concatenate([b["boxes"][:, others], b["boxes"][:, [3 + others[0], 3 + others[1]]]], 1)
+        assert np.array_equal(b["flat_boxes"], want)
+        own = (hi[occupied, fa] - lo[occupied, fa]).min()
+        assert 2 * half <= 1.5 * own * (1 + 1e-6)                     # never taken when a box is much narrower than the union
+
+
 def test_header_is_plain_c_and_links(tmp_path):
     """include/rtiow.h compiles as C99 (plain pointers and sizes, no C++), and a C program that references
     every declared entry point links against librtiow_hip.so — what a cgo / JNI / FFI binding relies on."""
@@ -247,8 +296,9 @@ def test_clustered_kernel_keeps_three_waves_per_simd():
         if m and name and "path_persistent_kernel" in name:
             assert int(m.group(1)) == 0, (name, "spills to scratch")
     # (the small-scene variant <true, true> comes from the second compilation of rtiow_kernels.hip: `make asm` runs both)
-    clustered = {k: v for k, v in seen.items() if re.search(r"path_persistent_kernelILb[01]ELb1EEEv", k)}
-    assert len(clustered) == 2, seen.keys()
+    # <shading records in LDS, clustered list, flat-axis box test>: small / large scenes x whole / flat boxes
+    clustered = {k: v for k, v in seen.items() if re.search(r"path_persistent_kernelILb[01]ELb1ELb[01]EEEv", k)}
+    assert len(clustered) == 4, seen.keys()
     for k, v in clustered.items():
         assert v <= 168, (k, v)
 

@@ -102,6 +102,7 @@ SIGNATURES = {
     "rtMultiGetLastError": (C.c_char_p, [_VP]),
     "rtMultiSelfTestHost": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _VP]),
     "rtChunkOrderSelfTestHost": (C.c_int, [C.c_uint32, _VP, _VP]),
+    "rtClusterBuildHost": (C.c_int, [_VP, C.c_uint32, C.c_float, _VP, _VP, C.c_uint32, _VP, _VP, _VP, C.c_uint32, _VP, _VP, _VP, _VP]),
     "rtConeSelfTestHost": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _VP, C.c_float, _VP, C.c_uint32,
                                      _VP, C.c_uint32, _VP, _VP]),
 }
@@ -399,6 +400,31 @@ def multi_selftest_host(full: np.ndarray, row_block: int, n_tiles: int) -> np.nd
     if code != RT_OK:
         raise RtError(code, "rtMultiSelfTestHost", (lib.rtMultiGetLastError(None) or b"").decode())
     return out
+
+
+def cluster_build_host(spheres: np.ndarray, range_diags: float = 2.0) -> dict:
+    """rtClusterBuildHost: the two-level list rtSetScene builds (no GPU involved) -- boxes [n, 6] of the clusters then the
+    super-clusters, slot_index [n_slots] (0xFFFFFFFF: padding), n_large_slots, flat_axis (3: none), flat_interval
+    (centre, half extent) and flat_boxes [n, 4]."""
+    lib = load_library()
+    spheres = np.ascontiguousarray(spheres, SPHERE_DTYPE)
+    cap = len(spheres) // 8 + 64
+    slot_cap = 2 * len(spheres) + 1024
+    boxes = np.zeros((cap, 6), np.float32)
+    flat = np.zeros((cap, 4), np.float32)
+    slots = np.zeros(slot_cap, np.uint32)
+    nc, ns, nslots, nlarge, axis = (C.c_uint32(0) for _ in range(5))
+    interval = (C.c_float * 2)()
+    code = lib.rtClusterBuildHost(spheres.ctypes.data, len(spheres), float(range_diags), boxes.ctypes.data, flat.ctypes.data, cap,
+                                  C.byref(nc), C.byref(ns), slots.ctypes.data, slot_cap, C.byref(nslots), C.byref(nlarge),
+                                  C.byref(axis), interval)
+    if code != RT_OK:
+        raise RtError(code, "rtClusterBuildHost", (lib.rtGetLastError(None) or b"").decode())
+    n = nc.value + ns.value
+    assert n <= cap and nslots.value <= slot_cap
+    return {"n_clusters": nc.value, "n_super": ns.value, "boxes": boxes[:n].copy(), "flat_boxes": flat[:n].copy(),
+            "slot_index": slots[:nslots.value].copy(), "n_large_slots": nlarge.value, "flat_axis": axis.value,
+            "flat_interval": (float(interval[0]), float(interval[1]))}
 
 
 def chunk_order_selftest_host(n_chunks: int) -> Tuple[int, int]:

@@ -556,6 +556,38 @@ int rtConeSelfTestHost(const RtCamera* cam, uint32_t width, uint32_t height, uin
                                      n_boxes, sphere_reach, box_reach);
 }
 
+int rtClusterBuildHost(const RtSphere* spheres, uint32_t n_spheres, float range_diags, float* boxes, float* flat_boxes,
+                       uint32_t box_cap, uint32_t* n_clusters, uint32_t* n_super, uint32_t* slot_index, uint32_t slot_cap,
+                       uint32_t* n_slots, uint32_t* n_large_slots, uint32_t* flat_axis, float* flat_interval) {
+    if (!spheres || n_spheres == 0 || !n_clusters || !n_super || !n_slots || !n_large_slots || !flat_axis || !flat_interval)
+        return fail(nullptr, RT_ERR_INVALID, "rtClusterBuildHost: null argument or empty scene");
+    rtiow::ClusterScene cs;
+    rtiow::build_clusters(spheres, n_spheres, range_diags, cs);  // the very function rtSetScene calls
+    *n_clusters = cs.n_clusters;
+    *n_super = cs.n_super;
+    *n_slots = static_cast<uint32_t>(cs.slots.size());
+    *n_large_slots = cs.n_large_slots;
+    *flat_axis = cs.flat_axis;
+    flat_interval[0] = cs.flat_mid;
+    flat_interval[1] = cs.flat_half;
+    const uint32_t n_boxes = cs.n_clusters + cs.n_super;
+    for (uint32_t b = 0; b < n_boxes && b < box_cap; ++b) {
+        if (boxes) {
+            const rtiow::ClusterF4 &mid = cs.bounds[2u * b], &half = cs.bounds[2u * b + 1u];
+            const float v[6] = {mid.x, mid.y, mid.z, half.x, half.y, half.z};
+            std::memcpy(boxes + 6u * b, v, sizeof v);
+        }
+        if (flat_boxes && cs.flat_axis < 3u) {
+            const rtiow::ClusterF4& f = cs.bounds[2u * n_boxes + b];
+            const float v[4] = {f.x, f.y, f.z, f.w};
+            std::memcpy(flat_boxes + 4u * b, v, sizeof v);
+        }
+    }
+    if (slot_index)
+        for (uint32_t k = 0; k < cs.idx.size() && k < slot_cap; ++k) slot_index[k] = cs.idx[k];
+    return RT_OK;
+}
+
 int rtChunkOrderSelfTestHost(uint32_t n_chunks, uint32_t* words_out, uint32_t* max_slot_out) {
     if (!words_out || !max_slot_out) return fail(nullptr, RT_ERR_INVALID, "rtChunkOrderSelfTestHost: null argument");
     // the very functions rtRender sizes the buffer with and the kernels index it with
