@@ -369,19 +369,26 @@ def run(args, np, torch, dist, V, D, world, rank, local_rank, backend, dev):
         # against the issue rate tools/ubench_valu.hip measures for back-to-back v_fma_f32 on this part
         # (2.53 cycles per wave instruction per SIMD at 2.4 GHz: 0.97e12 wave instructions / s)
         valu_issue = None
-        pmc_name = {2: "path_persistent_kernel<true,false>", 3: "path_persistent_kernel<true,true>"}.get(eff_kernel)
-        if world == 1 and pmc_name and args.workload == "cover_1200x800_100spp":
+        def pmc_kernel(pj):  # path_persistent_kernel<shading records in LDS, clustered list, flat-axis box test> of this variant
+            for name in pj:
+                if name.startswith("path_persistent_kernel<"):
+                    targs = name[name.index("<") + 1:name.rindex(">")].split(",")
+                    if len(targs) >= 2 and (targs[1] == "true") == (eff_kernel == 3):
+                        return name
+            raise KeyError("no path kernel in the profile")
+        if world == 1 and eff_kernel in (2, 3) and args.workload == "cover_1200x800_100spp":
             for ppath in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):  # newest round first
                 try:
                     pj = json.load(open(ppath))
                     if pj.get("kernel_source_sha16") != kernel_source_sha16():
                         break  # the newest profile is of other kernels than the tree holds: no figure rather than a stale one
+                    pmc_name = pmc_kernel(pj)
                     insts = pj[pmc_name]["SQ_INSTS_VALU"]["mean_per_launch"]
                     valu_issue = {"valu_wave_instructions_per_launch": insts,
                                   "rate": insts / (kernel_ms * 1e-3), "peak": VALU_ISSUE_PEAK, "unit": "wave instructions/s",
                                   "frac": insts / (kernel_ms * 1e-3) / VALU_ISSUE_PEAK,
                                   "lane_occupancy": pj[pmc_name].get("lane_occupancy_valu"),
-                                  "source": "profiles/" + os.path.basename(ppath),
+                                  "kernel": pmc_name, "source": "profiles/" + os.path.basename(ppath),
                                   "kernel_source_sha16": pj.get("kernel_source_sha16")}
                     break
                 except (OSError, KeyError, ValueError):
