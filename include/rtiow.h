@@ -122,8 +122,10 @@ typedef struct RtParams {
                             clustered list; 4 = 3 with the primary pass (camera rays traced where they are
                             made, against the spheres their pixels' cones reach) at any spp -- 0 and 3 use
                             it from 8 samples per pixel on (scenes too large for their shading records to
-                            sit in LDS: always); rtGetLastKernel reports 3.  Frames are
-                            identical by contract. */
+                            sit in LDS: always); rtGetLastKernel reports 3.  RT_MODE_CH05 / RT_MODE_CH06 through
+                            rtRender: 1 = one lane per pixel in 16x16 tiles, the shape raytrace06.comp:2 and
+                            RTCHAP06/main.cpp:321 dispatch; anything else = four pixels of a row per lane
+                            (rows kernel).  Frames are identical by contract. */
     /* Progressive accumulation, the frame loop of RTCHAP06/main.cpp:304-360 with a running
      * average: with accumulate != 0 this dispatch adds samples sample_offset .. sample_offset+spp-1
      * of every pixel to accumulators the context keeps (reset when sample_offset == 0) and writes
