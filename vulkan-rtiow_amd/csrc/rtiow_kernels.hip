@@ -904,6 +904,33 @@ DI uint32_t wave_inclusive_sum(uint32_t v) {
     return v;
 }
 
+// Square root, reciprocal square root and reciprocal for the CULLS of the primary pass (cone_of_span, cone_reaches,
+// cone_reaches_sphere): on the device the one-instruction forms (v_sqrt_f32, v_rsq_f32, v_rcp_f32: 1 ulp), on the host the
+// exact ones.  The culls carry relative margins of 2^-6 .. 2^-8 and an absolute one of 2^-16 of the scene's range; an ulp
+// is 2^-24.  (The correctly rounded sqrt and division cost 12 and 11 instructions each: 53 per pass saved.)  cull_sqrt
+// is nudged up by two ulps so that it never falls below the exact root.
+HDI float cull_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RTIOW_EXACT_CULL)  // (-DRTIOW_EXACT_CULL: A/B only)
+    return __builtin_amdgcn_sqrtf(x) * 1.00000024f;
+#else
+    return __builtin_sqrtf(x);
+#endif
+}
+HDI float cull_rsqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RTIOW_EXACT_CULL)  // (-DRTIOW_EXACT_CULL: A/B only)
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.0f / __builtin_sqrtf(x);
+#endif
+}
+HDI float cull_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RTIOW_EXACT_CULL)  // (-DRTIOW_EXACT_CULL: A/B only)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
 HDI float slab_rcp(float d) {  // reciprocal of a direction component kept away from zero (finite slabs, no NaN)
     const float c = __builtin_fabsf(d) < 1e-18f ? __builtin_copysignf(1e-18f, d) : d;
 #ifdef __HIP_DEVICE_COMPILE__
@@ -1640,14 +1667,14 @@ HDI ConeAxis cone_of_span(const PathArgs& a, const PersistArgs& g, uint32_t pix_
     const float dy = fma_(vc, c.vertical[1], fma_(uc, c.horizontal[1], c.lower_left[1])) - c.origin[1];
     const float dz = fma_(vc, c.vertical[2], fma_(uc, c.horizontal[2], c.lower_left[2])) - c.origin[2];
     const float len2 = fma_(dz, dz, fma_(dy, dy, dx * dx));
-    const float inv_len = 1.0f / __builtin_sqrtf(len2);
+    const float inv_len = cull_rsqrt(len2);  // (the axis need only be a unit vector to a few ulps: the cone's margins are 2^-8)
     ConeAxis o;
     o.dnx = dx * inv_len;
     o.dny = dy * inv_len;
     o.dnz = dz * inv_len;
     o.kappa = (g.lens_rho + rho_t) * inv_len;
     o.all = !(o.kappa < 0.125f);  // (also a NaN or an axis of length 0)
-    o.inv1mk = 1.00390625f / (1.0f - o.kappa);
+    o.inv1mk = 1.00390625f * cull_rcp(1.0f - o.kappa);
     o.ix = slab_rcp(o.dnx);
     o.iy = slab_rcp(o.dny);
     o.iz = slab_rcp(o.dnz);
@@ -1694,7 +1721,7 @@ HDI bool cone_reaches_sphere(const PathArgs& a, const PersistArgs& g, const Cone
     const float ee = fma_(ez, ez, fma_(ey, ey, ex * ex));
     const float cx = ey * c.dnz - ez * c.dny, cy = ez * c.dnx - ex * c.dnz, cz = ex * c.dny - ey * c.dnx;
     const float d2 = proj > 0.0f ? fma_(cz, cz, fma_(cy, cy, cx * cx)) : ee;
-    const float rr = __builtin_sqrtf(fma_(0x1p-17f, fma_(g.lens_rho, g.lens_rho, ee), s.w)) + g.abs_margin;
+    const float rr = cull_sqrt(fma_(0x1p-17f, fma_(g.lens_rho, g.lens_rho, ee), s.w)) + g.abs_margin;
     const float s_far = ((proj > 0.0f ? proj : 0.0f) + rr + g.lens_rho) * c.inv1mk;
     const float lim = rr + (fma_(c.kappa, s_far, g.lens_rho) * 1.00390625f + g.abs_margin);
     return s.w >= 0.0f && (c.all || !(d2 > lim * lim));  // (padding slots have r^2 = -inf; a NaN reaches)
