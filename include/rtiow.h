@@ -175,8 +175,8 @@ int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materi
  *      hazard of main.cpp:324 vs :354).
  *      One exception to "enqueues and returns": a camera that has moved beyond 0.95 of the range the
  *      cluster boxes were inflated for (2 scene diagonals at rtSetScene), or back within an eighth of
- *      it, has the boxes rebuilt inside this call -- hipDeviceSynchronize, which also drains other
- *      contexts' frames on the same device, then a re-upload.  Rare (a fly-away camera), never wrong. */
+ *      it, has the boxes rebuilt inside this call: the host waits for THIS context's previous frame (other
+ *      contexts' frames on the device are not touched), then re-uploads.  Rare (a fly-away camera), never wrong. */
 int rtRender(RtContext* ctx, const RtCamera* cam, const RtParams* params, void* dst,
              size_t dst_pitch, int dst_is_device, void* stream);
 

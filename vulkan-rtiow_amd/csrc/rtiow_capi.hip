@@ -129,18 +129,27 @@ int rtDestroy(RtContext* ctx) {
 static int upload_clusters(RtContext* ctx, double range_diags) {
     rtiow::ClusterScene cs;
     rtiow::build_clusters(ctx->host_spheres.data(), static_cast<uint32_t>(ctx->host_spheres.size()), range_diags, cs);
-    if (ctx->d_cslots) RT_HIP(ctx, hipFree(ctx->d_cslots));
-    if (ctx->d_cidx) RT_HIP(ctx, hipFree(ctx->d_cidx));
-    if (ctx->d_cbounds) RT_HIP(ctx, hipFree(ctx->d_cbounds));
-    ctx->d_cslots = nullptr;
-    ctx->d_cidx = nullptr;
-    ctx->d_cbounds = nullptr;
-    RT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_cslots), sizeof(float4) * cs.slots.size()));
-    RT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_cidx), sizeof(uint32_t) * cs.idx.size()));
-    RT_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_cbounds), sizeof(float4) * cs.bounds.size()));
-    RT_HIP(ctx, hipMemcpy(ctx->d_cslots, cs.slots.data(), sizeof(float4) * cs.slots.size(), hipMemcpyHostToDevice));
-    RT_HIP(ctx, hipMemcpy(ctx->d_cidx, cs.idx.data(), sizeof(uint32_t) * cs.idx.size(), hipMemcpyHostToDevice));
-    RT_HIP(ctx, hipMemcpy(ctx->d_cbounds, cs.bounds.data(), sizeof(float4) * cs.bounds.size(), hipMemcpyHostToDevice));
+    // (Re-)allocate only when the lists have grown -- re-boxing the same spheres for another range never does: hipFree
+    // synchronises the whole device, and other contexts may have frames in flight on it.  The copies go through the
+    // context's own stream (the caller has made sure no frame of this context still reads the old lists).
+    auto room = [&](void** p, size_t* cap, size_t bytes) -> int {
+        if (*cap >= bytes && *p) return RT_OK;
+        if (*p) RT_HIP(ctx, hipFree(*p));
+        *p = nullptr;
+        *cap = 0;
+        RT_HIP(ctx, hipMalloc(p, bytes));
+        *cap = bytes;
+        return RT_OK;
+    };
+    const size_t n_boxes = size_t(cs.n_clusters) + cs.n_super;
+    int rc = room(reinterpret_cast<void**>(&ctx->d_cslots), &ctx->cslots_bytes, sizeof(float4) * cs.slots.size());
+    if (rc == RT_OK) rc = room(reinterpret_cast<void**>(&ctx->d_cidx), &ctx->cidx_bytes, sizeof(uint32_t) * cs.idx.size());
+    if (rc == RT_OK) rc = room(reinterpret_cast<void**>(&ctx->d_cbounds), &ctx->cbounds_bytes, sizeof(float4) * 3u * n_boxes);  // (whole boxes + flat ones)
+    if (rc != RT_OK) return rc;
+    RT_HIP(ctx, hipMemcpyAsync(ctx->d_cslots, cs.slots.data(), sizeof(float4) * cs.slots.size(), hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(ctx->d_cidx, cs.idx.data(), sizeof(uint32_t) * cs.idx.size(), hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(ctx->d_cbounds, cs.bounds.data(), sizeof(float4) * cs.bounds.size(), hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (`cs` goes out of scope; and any stream may render next)
     ctx->n_clusters = cs.n_clusters;
     ctx->n_super = cs.n_super;
     ctx->n_large = cs.n_large;
@@ -171,6 +180,8 @@ int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materi
             return fail(ctx, RT_ERR_INVALID, "rtSetScene: zero or NaN radius");
     }
     RT_HIP(ctx, hipSetDevice(ctx->device));
+    // (no frame of this context may still read the old scene: its last render may have gone to a caller's stream)
+    if (ctx->have_done) RT_HIP(ctx, hipEventSynchronize(ctx->ev_done));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_spheres) RT_HIP(ctx, hipFree(ctx->d_spheres));
     if (ctx->d_shade) RT_HIP(ctx, hipFree(ctx->d_shade));
@@ -343,7 +354,10 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
             if (!(need <= 64.0)) {
                 kernel = rtiow::KERNEL_PERSISTENT;
             } else if (need > 0.95 * ctx->cluster_range || (ctx->cluster_range > 2.0 && need < ctx->cluster_range / 8.0)) {
-                RT_HIP(ctx, hipDeviceSynchronize());
+                // (the old lists are read by this context's frames only: wait for the last of them -- ev_done marks the end
+                // of everything the previous render enqueued -- not for the device, where other contexts' frames are in flight)
+                if (ctx->have_done) RT_HIP(ctx, hipEventSynchronize(ctx->ev_done));
+                RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 int rc = upload_clusters(ctx, 2.0 * need);
                 if (rc != RT_OK) return rc;
                 a.cslots = ctx->d_cslots;
@@ -513,6 +527,11 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
             }
             fprintf(stderr, "iterations after dry: max %u, sum %llu\nqueue 0 head at k/8 of its pixels (us):", c.tl_tail_iters_max, c.tl_tail_iters_sum);
             for (int k = 1; k <= 8; ++k) fprintf(stderr, " %.0f", c.tl_progress[k] * 0.01);
+            fprintf(stderr, "\nentry-starved iterations: sum %llu, max per wave %u; live paths at dry: max %u, waves by 16s:", c.tl_starved_sum,
+                    c.tl_starved_max, c.tl_live_at_dry_max);
+            for (int b = 0; b < 9; ++b) fprintf(stderr, " %u", c.tl_live_at_dry_hist[b]);
+            fprintf(stderr, "; of the waves dry > 100 us after the first:");
+            for (int b = 0; b < 9; ++b) fprintf(stderr, " %u", c.tl_late_dry_live_hist[b]);
             fprintf(stderr, "\nfrom the first sparse iteration on: %llu iterations, %.2f us each, %.1f paths each\n", c.tl_sparse_iters_sum,
                     c.tl_sparse_iters_sum ? c.tl_sparse_ticks_sum * 0.01 / c.tl_sparse_iters_sum : 0.0,
                     c.tl_sparse_iters_sum ? double(c.tl_sparse_paths_sum) / c.tl_sparse_iters_sum : 0.0);

@@ -34,6 +34,7 @@ struct RtContext {
     float4* d_cslots = nullptr;   // clustered list (rtiow_clusters.cpp)
     uint32_t* d_cidx = nullptr;
     float4* d_cbounds = nullptr;
+    size_t cslots_bytes = 0, cidx_bytes = 0, cbounds_bytes = 0;  // capacities (re-boxing reuses the buffers)
     uint32_t n_clusters = 0, n_super = 0, n_large = 0, n_large_slots = 0, n_cslots = 0;
     uint32_t flat_axis = 3;       // (rtiow_clusters.cpp: the axis all cluster boxes share an interval along; 3: none)
     float flat_mid = 0, flat_half = 0;

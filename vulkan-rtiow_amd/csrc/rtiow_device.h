@@ -41,6 +41,11 @@ struct Counters {
     unsigned int tl_tail_iters_max, tl_pad;
     unsigned long long tl_tail_iters_sum;
     unsigned long long tl_sparse_iters_sum, tl_sparse_paths_sum, tl_sparse_ticks_sum;  // from a wave's first sparse iteration on
+    unsigned long long tl_starved_sum;      // iterations in which a wave could not open a pixel for want of an accumulator entry
+    unsigned int tl_starved_max, tl_live_at_dry_max;
+    unsigned int tl_live_at_dry_hist[9];    // waves by their live paths when they found the queues dry (bins of 16)
+    unsigned int tl_late_dry_live_hist[9];  // the same for the waves that ran dry more than 100 us after the first one
+    unsigned long long not_first_dry;       // ~(earliest dry stamp)
 };
 
 // Device-side shading record of one sphere (32 B), built by rtSetScene from RtSphere + RtMaterial.

@@ -665,6 +665,7 @@ struct PersistArgs {
     uint32_t pool_pix;     // pixels per pool away from the tail
     uint32_t chunk_pool;   // pixels per pool while whole chunks are handed out (a multiple of kChunkPix)
     uint32_t chunk_until;  // ... which lasts while a queue has at least this many pixels left
+    uint32_t fine_until;   // the first pixels of a queue's small-pool part that go out ONE at a time (0: none)
     // the primary pass of the clustered kernels (see "The primary pass" below)
     uint32_t use_pass;     // != 0: camera rays take the primary pass (enough samples per pixel), 0: straight into the slots
     uint32_t pass_keep;    // camera paths a wave may keep in LDS beyond its idle slots (records of its own; 0: none)
@@ -1864,6 +1865,9 @@ DI void primary_trace(const float4* slots, const uint32_t* idx_map, const float4
 // VGPRs: 84 registers spill to scratch and the cover frame takes 10.6 ms instead of 9.8, as in round 1.)
 #define RTIOW_SMALL_MAX_THREADS 512
 #endif
+#ifndef RTIOW_SMALL_WAVES_PER_EU
+#define RTIOW_SMALL_WAVES_PER_EU 1  // (no constraint: the small-scene variants find their three waves per SIMD by themselves)
+#endif
 #ifndef RTIOW_ACCEL_MAX_THREADS
 #define RTIOW_ACCEL_MAX_THREADS 768
 #endif
@@ -1892,7 +1896,7 @@ constexpr int kAccelMaxThreads = RTIOW_ACCEL_MAX_THREADS;
 // FLAT (clustered kernels): the scene's cluster boxes share one interval along a.flat_axis, and the lock-step box tests
 // leave that axis out (slab_gap_flat).
 template <bool SHADE_LDS, bool ACCEL, bool FLAT = false>
-__global__ __launch_bounds__(ACCEL ? (SHADE_LDS ? RTIOW_SMALL_MAX_THREADS : kAccelMaxThreads) : 1024) __attribute__((amdgpu_waves_per_eu(ACCEL && !SHADE_LDS ? 3 : 1)))
+__global__ __launch_bounds__(ACCEL ? (SHADE_LDS ? RTIOW_SMALL_MAX_THREADS : kAccelMaxThreads) : 1024) __attribute__((amdgpu_waves_per_eu(ACCEL && !SHADE_LDS ? 3 : RTIOW_SMALL_WAVES_PER_EU)))
 void path_persistent_kernel(PathArgs a, PersistArgs g) {
     static_assert(ACCEL || !FLAT, "only the clustered list has boxes");
     // LDS: sphere list [g.n_pad float4] — the flat list, or (ACCEL) the clustered list's slots, then
@@ -1967,6 +1971,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     uint32_t whole_done = 0u;                // bit q: the whole-chunk part of queue q is known to be handed out
     uint32_t rest_done = 0u;                 // ... and the rest of it
     bool pool_owned = false;                 // the pool is whole chunks of the frame that only this wave renders
+    bool pool_fine = g.fine_until != 0u;     // the wave's next small pool is a single pixel (the dear head of an ordered queue)
     uint32_t cur_line = 0u;                  // line buffer of the chunk being handed out, + 1 (0: its pixels go straight to the frame)
     [[maybe_unused]] uint32_t pass_n = 0u;   // (clustered) camera paths waiting in the wave's LDS records for an idle slot
     [[maybe_unused]] bool exhausted = false; // the global queue has been drained
@@ -1974,7 +1979,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     const unsigned long long tl_start = wall_clock64();
     if (lane == 0u) atomicMax(&a.counters->not_t0, ~tl_start);
     unsigned long long tl_dry = 0ull, tl_sparse = 0ull;
-    uint32_t tl_tail_iters = 0u, tl_sparse_iters = 0u, tl_sparse_paths = 0u;
+    uint32_t tl_tail_iters = 0u, tl_sparse_iters = 0u, tl_sparse_paths = 0u, tl_starved = 0u, tl_live_at_dry = ~0u;
 #endif
     uint32_t n_paths = 0, n_segments = 0, n_tests = 0;
     [[maybe_unused]] uint32_t dbg_slow_trips = 0, dbg_cands = 0, dbg_iters = 0, dbg_sparse = 0;
@@ -2145,10 +2150,16 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                             // traffic, 1.3 MB per frame.)
                             const uint32_t rest = vsize - wsize;
                             if (((rest_done >> xq) & 1u) == 0u) {
-                                const uint32_t k = g.pool_pix;
+                                // The head of an ORDERED queue holds the dearest pixels of the frame -- the rim of the glass ball: a
+                                // hundred samples that nearly all bounce fifty times -- and a pool is one wave's work whatever it holds:
+                                // on a small frame four such pixels in one wave's hands are the whole frame's time (one eighth of the cover
+                                // frame, tile 5: 1.60 ms with pools of 4, 2.0 with 8, 1.36 with 1; tools/tile_ranks.py).  So the first
+                                // g.fine_until pixels of a queue go out one at a time (judged by the wave's last fetch: no look at the head).
+                                const uint32_t k = pool_fine ? 1u : g.pool_pix;
                                 uint32_t got = 0u;
                                 if (lane == 0u) got = atomicAdd(&a.counters->xcd_head[xq].next, k);
                                 got = __builtin_amdgcn_readfirstlane(got);
+                                pool_fine = wsize + got + k < g.fine_until;
 #ifdef RTIOW_DEBUG_TIMELINE
                                 if (xq == 0u && lane == 0u && got < rest && (wsize + got) * 8u / vsize != (wsize + got + k) * 8u / vsize) {
                                     const unsigned long long t0w = ~__hip_atomic_load(&a.counters->not_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2205,7 +2216,12 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                         ++pool_next;
                         continue;
                     }
-                    if (free_entries == 0ull) break;  // 64 pixels in flight: wait for one to finish
+                    if (free_entries == 0ull) {  // 64 pixels in flight: wait for one to finish
+#ifdef RTIOW_DEBUG_TIMELINE
+                        ++tl_starved;
+#endif
+                        break;
+                    }
                     cur_entry = static_cast<uint32_t>(__builtin_ctzll(free_entries));
                     free_entries &= free_entries - 1ull;
                     cur_pix = pix;
@@ -2431,6 +2447,10 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         if (__ballot(any_active) == 0ull) break;
 #ifdef RTIOW_DEBUG_TIMELINE
         if (tl_dry != 0ull) ++tl_tail_iters;
+        if (tl_dry != 0ull && tl_live_at_dry == ~0u) {
+            tl_live_at_dry = static_cast<uint32_t>(__popcll(__ballot(sl[0].active)) + __popcll(__ballot(sl[1].active))) + pass_n;
+            if (lane == 0u) atomicMax(&a.counters->not_first_dry, ~tl_dry);
+        }
 #endif
         [[maybe_unused]] const unsigned long long t1 = DBG_STAMP();
 
@@ -2558,6 +2578,15 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             atomicAdd(&a.counters->tl_hist[k][b > 63ull ? 63ull : b], 1u);
         }
         atomicMax(&a.counters->tl_tail_iters_max, tl_tail_iters);
+        atomicAdd(&a.counters->tl_starved_sum, static_cast<unsigned long long>(tl_starved));
+        atomicMax(&a.counters->tl_starved_max, tl_starved);
+        if (tl_live_at_dry != ~0u) {
+            atomicMax(&a.counters->tl_live_at_dry_max, tl_live_at_dry);
+            atomicAdd(&a.counters->tl_live_at_dry_hist[tl_live_at_dry / 16u > 8u ? 8u : tl_live_at_dry / 16u], 1u);
+            const unsigned long long first_dry = ~__hip_atomic_load(&a.counters->not_first_dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tl_dry > first_dry + 10000ull)
+                atomicAdd(&a.counters->tl_late_dry_live_hist[tl_live_at_dry / 16u > 8u ? 8u : tl_live_at_dry / 16u], 1u);
+        }
         atomicAdd(&a.counters->tl_tail_iters_sum, static_cast<unsigned long long>(tl_tail_iters));
         if (tl_sparse != 0ull) {
             atomicAdd(&a.counters->tl_sparse_iters_sum, static_cast<unsigned long long>(tl_sparse_iters));
@@ -2989,6 +3018,13 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // chunks against 10.5 without (9.6 once the order is there).
     if (a.chunk_order == nullptr) g.chunk_until = ~0u;
     if (const char* v = getenv("RTIOW_DEBUG_CHUNK_UNTIL")) g.chunk_until = strtoul(v, nullptr, 10);
+    // ... and where no whole chunks are handed out -- small frames -- the head of an ORDERED queue, its dearest eighth, goes out
+    // pixel by pixel (see the fetch): a queue has total_pix / 8 pixels (RTIOW_DEBUG_FINE_DIV: tuning only; 0 switches it off)
+    {
+        uint32_t div = 8u;
+        if (const char* v = getenv("RTIOW_DEBUG_FINE_DIV")) div = strtoul(v, nullptr, 10);
+        g.fine_until = (g.chunk_until == ~0u && a.chunk_order != nullptr && div != 0u && g.pool_pix > 1u) ? g.total_pix / 8u / div : 0u;
+    }
     hipLaunchKernelGGL(kernel_fn, dim3(static_cast<uint32_t>(grid)), dim3(threads), lds, stream, a, g);
     return hipGetLastError();
 }
