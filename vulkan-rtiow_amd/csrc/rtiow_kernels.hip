@@ -665,7 +665,8 @@ struct PersistArgs {
     uint32_t pool_pix;     // pixels per pool away from the tail
     uint32_t chunk_pool;   // pixels per pool while whole chunks are handed out (a multiple of kChunkPix)
     uint32_t chunk_until;  // ... which lasts while a queue has at least this many pixels left
-    uint32_t fine_until;   // the first pixels of a queue's small-pool part that go out ONE at a time (0: none)
+    uint32_t fine_until;   // the first pixels of a queue's small-pool part that go out fine_pix at a time (0: none)
+    uint32_t fine_pix;     // ... one iteration's worth of samples: 128 / spp pixels, at least one
     // the primary pass of the clustered kernels (see "The primary pass" below)
     uint32_t use_pass;     // != 0: camera rays take the primary pass (enough samples per pixel), 0: straight into the slots
     uint32_t pass_keep;    // camera paths a wave may keep in LDS beyond its idle slots (records of its own; 0: none)
@@ -2154,8 +2155,9 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                                 // hundred samples that nearly all bounce fifty times -- and a pool is one wave's work whatever it holds:
                                 // on a small frame four such pixels in one wave's hands are the whole frame's time (one eighth of the cover
                                 // frame, tile 5: 1.60 ms with pools of 4, 2.0 with 8, 1.36 with 1; tools/tile_ranks.py).  So the first
-                                // g.fine_until pixels of a queue go out one at a time (judged by the wave's last fetch: no look at the head).
-                                const uint32_t k = pool_fine ? 1u : g.pool_pix;
+                                // g.fine_until pixels of a queue go out an iteration's worth of samples at a time -- one pixel at 100 spp
+                                // (judged by the wave's last fetch: no look at the head).
+                                const uint32_t k = pool_fine ? g.fine_pix : g.pool_pix;
                                 uint32_t got = 0u;
                                 if (lane == 0u) got = atomicAdd(&a.counters->xcd_head[xq].next, k);
                                 got = __builtin_amdgcn_readfirstlane(got);
@@ -3023,7 +3025,8 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     {
         uint32_t div = 8u;
         if (const char* v = getenv("RTIOW_DEBUG_FINE_DIV")) div = strtoul(v, nullptr, 10);
-        g.fine_until = (g.chunk_until == ~0u && a.chunk_order != nullptr && div != 0u && g.pool_pix > 1u) ? g.total_pix / 8u / div : 0u;
+        g.fine_pix = 128u / a.spp < 1u ? 1u : 128u / a.spp;  // (a 1-spp frame: 128 pixels -- more than its pools hold, i.e. no fine dealing)
+        g.fine_until = (g.chunk_until == ~0u && a.chunk_order != nullptr && div != 0u && g.pool_pix > g.fine_pix) ? g.total_pix / 8u / div : 0u;
     }
     hipLaunchKernelGGL(kernel_fn, dim3(static_cast<uint32_t>(grid)), dim3(threads), lds, stream, a, g);
     return hipGetLastError();
