@@ -91,6 +91,37 @@ def test_ch_row_kernel_equals_the_tiled_form_and_the_oracle(gpu_ctx, oracle, mod
         assert np.array_equal(got[:, :w].copy().view(np.uint8).reshape(h, w, 4), want), pad
 
 
+@pytest.mark.parametrize("mode", [V.RT_MODE_CH05, V.RT_MODE_CH06])
+def test_ch_lean_roots_and_quotients_equal_the_full_forms_and_the_oracle(gpu_ctx, oracle, mode, monkeypatch):
+    """ch_kernel_rows takes its square roots and quotients without hipcc's range handling (ch_sqrt, ch_div: the cores of
+    the correctly rounded expansions) when the camera's proportions are moderate, and with the full forms otherwise
+    (RTIOW_DEBUG_CH_FULL forces those): random UBOs -- viewports and focal lengths over six orders of magnitude, the
+    sphere anywhere from a dot to larger than the frame -- must give the oracle's bytes either way; so must UBOs outside the
+    lean range (tiny, huge and negative viewports)."""
+    rng = np.random.default_rng(mode)
+    ubos = []
+    for _ in range(24):
+        w, h = int(rng.integers(2, 700)), int(rng.integers(2, 300))
+        u = V.ubo_from_image(w, h)
+        u.viewportWidth = float(np.float32(10.0 ** rng.uniform(-3, 3)))
+        u.viewportHeight = float(np.float32(10.0 ** rng.uniform(-3, 3)))
+        u.focalLength = float(np.float32(10.0 ** rng.uniform(-3, 3)))
+        ubos.append(u)
+    for vw, vh, f in ((1e-9, 2.0, 1.0), (2.0, 3e8, 1.0), (2.0, 1.0, 1e-12), (-2.0, 1.125, 1.0), (2.0, -1.0, 5e7)):
+        u = V.ubo_from_image(96, 64)
+        u.viewportWidth, u.viewportHeight, u.focalLength = vw, vh, f
+        ubos.append(u)
+    for u in ubos:
+        want = oracle.render_ubo(u, mode)
+        monkeypatch.delenv("RTIOW_DEBUG_CH_FULL", raising=False)
+        lean = gpu_ctx.render_ubo(u, mode)
+        monkeypatch.setenv("RTIOW_DEBUG_CH_FULL", "1")
+        full = gpu_ctx.render_ubo(u, mode)
+        what = (u.imageWidth, u.imageHeight, u.viewportWidth, u.viewportHeight, u.focalLength)
+        assert np.array_equal(full, want), (what, _diff(full, want))
+        assert np.array_equal(lean, want), (what, _diff(lean, want))
+
+
 def test_ch_known_answers_on_gpu(gpu_ctx):
     """SURVEY 8(c) table straight against the HIP kernel (no oracle in the loop)."""
     for row in json.load(open(os.path.join(GOLD, "ch_known_answers.json"))):

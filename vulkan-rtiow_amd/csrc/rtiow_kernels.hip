@@ -238,8 +238,39 @@ DI uint32_t ch_unorm8(float x) {
     return q < 255u ? q : 255u;
 }
 
+// Correctly rounded square root and quotient WITHOUT the range handling hipcc wraps around them (LEAN instantiation).
+// hipcc expands sqrtf(x) into v_sqrt_f32 (1 ulp) and a check of the two neighbouring floats against the residual --
+// after multiplying x by 2^32 when it lies below 2^-96, and with a class test for 0 / inf / NaN at the end: 16
+// instructions, of which the 10 of ch_sqrt are the core; it expands a / b into v_rcp_f32, one Newton step on the reciprocal
+// and three on the quotient between v_div_scale_f32 (which rescales operands whose exponents are extreme or far apart),
+// v_div_fmas_f32 and v_div_fixup_f32 (which put the scale back and deal with 0 / inf / NaN / denormals): 12 instructions,
+// of which the 8 of ch_div are the core.  Where no rescaling happens the full forms ARE the cores, instruction for
+// instruction, so the results are bit-identical: for x == 0 or x >= 2^-96, and for a == 0 or normal a, b with exponents
+// less than 96 apart and a normal quotient.  launch_ch selects the LEAN kernels only for a UBO whose viewport and focal
+// length lie in [2^-20, 2^20]: every square root the shaders take is then 0 or at least 2^-63 (a difference of two
+// numbers of at least 2^-40 in magnitude, or a sum of squares), every divisor between 2^-21 and 2^22, every dividend
+// 0 or at least 2^-44.  (One difference that cannot reach a pixel: -0 / b comes out as +0; each quotient of the shaders
+// is added to 1 or compared with 0 next.)
+DI float ch_sqrt(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = fma_(-s_dn, s, x), r_up = fma_(-s_up, s, x);
+    const float r = (0.0f >= r_dn) ? s_dn : s;
+    return (0.0f < r_up) ? s_up : r;
+}
+DI float ch_div(float a, float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float r1 = fma_(fma_(-b, r0, 1.0f), r0, r0);
+    const float q0 = a * r1;
+    const float q1 = fma_(fma_(-b, q0, a), r1, q0);
+    return fma_(fma_(-b, q1, a), r1, q1);
+}
+
 // one pixel: raytrace06.comp:21-48 / raytrace05.comp:21-40 from the hoisted products (xx = dir.x*dir.x, ox = oc.x*dir.x, ...)
+template <bool LEAN>
 DI uint32_t ch_pixel(uint32_t mode, const ChConst& k, float dx, float xx, float ox, float dy, float yy, float oy) {
+    auto sqrt_ = [](float x) { return LEAN ? ch_sqrt(x) : __builtin_sqrtf(x); };
+    auto div_ = [](float a, float b) { return LEAN ? ch_div(a, b) : a / b; };
     const float qa = (xx + yy) + k.zz;             // gdot(dir, dir)
     const float qb = 2.0f * ((ox + oy) + k.oz_dz);   // 2 * gdot(oc, dir)
     const float disc = qb * qb - 4 * qa * k.qc;
@@ -251,16 +282,18 @@ DI uint32_t ch_pixel(uint32_t mode, const ChConst& k, float dx, float xx, float 
             shaded = true;
         }
     } else {
-        const float t = (disc < 0) ? -1.0f : (-qb - __builtin_sqrtf(disc)) / (2.0f * qa);
+        const float t = (disc < 0) ? -1.0f : div_(-qb - sqrt_(disc), 2.0f * qa);
         if (t > 0.0f) {  // raytrace06.comp:39-43
             const f3 r = mk(0.0f + dx * t, 0.0f + dy * t, 0.0f + k.dz * t);
-            const f3 nrm = gnormalize(mk(r.x - 0.0f, r.y - 0.0f, r.z - (-1.0f)));
+            const f3 v = mk(r.x - 0.0f, r.y - 0.0f, r.z - (-1.0f));
+            const float l = sqrt_(gdot(v, v));  // normalize(v) = v / sqrt(dot(v, v))
+            const f3 nrm = mk(div_(v.x, l), div_(v.y, l), div_(v.z, l));
             col = mk(0.5f * (nrm.x + 1), 0.5f * (nrm.y + 1), 0.5f * (nrm.z + 1));
             shaded = true;
         }
     }
     if (!shaded) {  // raytrace06.comp:45-47: only the y component of normalize(dir) is used
-        const float unit_y = dy / __builtin_sqrtf(qa);
+        const float unit_y = div_(dy, sqrt_(qa));
         const float t = 0.5f * (unit_y + 1.0f);
         const float kk = 1.0f - t;
         col = mk(1.0f * kk + 0.5f * t, 1.0f * kk + 0.7f * t, 1.0f * kk + 1.0f * t);
@@ -269,6 +302,7 @@ DI uint32_t ch_pixel(uint32_t mode, const ChConst& k, float dx, float xx, float 
 }
 
 constexpr uint32_t kChTileCols = 256;  // columns of a workgroup's tile: 64 lanes x 4 pixels
+template <bool LEAN>
 __global__ __launch_bounds__(256) void ch_kernel_rows(ChArgs a) {
     __shared__ float4 col_dx[kChTileCols / 4], col_xx[kChTileCols / 4], col_ox[kChTileCols / 4];  // per column, four to a lane
     __shared__ float row_dy[64], row_yy[64], row_oy[64];                                          // per row of the tile
@@ -301,10 +335,10 @@ __global__ __launch_bounds__(256) void ch_kernel_rows(ChArgs a) {
         if (row >= a.height) break;
         const float dy = row_dy[lr], yy = row_yy[lr], oy = row_oy[lr];  // LDS broadcast
         uint4 px;
-        px.x = ch_pixel(a.mode, k, dx4.x, xx4.x, ox4.x, dy, yy, oy);
-        px.y = ch_pixel(a.mode, k, dx4.y, xx4.y, ox4.y, dy, yy, oy);
-        px.z = ch_pixel(a.mode, k, dx4.z, xx4.z, ox4.z, dy, yy, oy);
-        px.w = ch_pixel(a.mode, k, dx4.w, xx4.w, ox4.w, dy, yy, oy);
+        px.x = ch_pixel<LEAN>(a.mode, k, dx4.x, xx4.x, ox4.x, dy, yy, oy);
+        px.y = ch_pixel<LEAN>(a.mode, k, dx4.y, xx4.y, ox4.y, dy, yy, oy);
+        px.z = ch_pixel<LEAN>(a.mode, k, dx4.z, xx4.z, ox4.z, dy, yy, oy);
+        px.w = ch_pixel<LEAN>(a.mode, k, dx4.w, xx4.w, ox4.w, dy, yy, oy);
         uint32_t* out = a.dst + static_cast<size_t>(row) * a.dst_stride + c;
         if (vec) {
             *reinterpret_cast<uint4*>(out) = px;
@@ -2810,7 +2844,12 @@ hipError_t launch_ch(const ChArgs& args, hipStream_t stream) {
     a.rows_per_wave = rpw;
     a.vector_store = (reinterpret_cast<uintptr_t>(a.dst) % 16u == 0u && a.dst_stride % 4u == 0u) ? 1u : 0u;
     const uint32_t blocks = tiles_x * ((a.height + 4u * rpw - 1u) / (4u * rpw));
-    hipLaunchKernelGGL(ch_kernel_rows, dim3(blocks), dim3(256), 0, stream, a);
+    // the lean square roots and quotients (ch_sqrt, ch_div) for a camera of moderate proportions, hipcc's full forms otherwise
+    auto moderate = [](float v) { return std::fabs(v) >= 0x1p-20f && std::fabs(v) <= 0x1p20f; };
+    const bool lean = moderate(a.ubo.viewportWidth) && moderate(a.ubo.viewportHeight) && moderate(a.ubo.focalLength) &&
+                      !getenv("RTIOW_DEBUG_CH_FULL");  // (the variable: A/B and parity tests)
+    if (lean) hipLaunchKernelGGL(ch_kernel_rows<true>, dim3(blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(ch_kernel_rows<false>, dim3(blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
