@@ -7,11 +7,12 @@
 //                           image sizes; RtParams.kernel = 1: the form the row kernel is checked against)
 //   path_pixel_kernel       PATH mode v1 (RtParams.kernel 1): one lane per pixel, spp + bounce loops inside, sphere
 //                           list staged in LDS once per workgroup; kept as a cross-check and ablation
-//   path_persistent_kernel  PATH mode v2, four instantiations <shading records in LDS?, clustered list?>: persistent
-//                           waves, two path slots per lane, per-XCD pixel queues, LDS accumulators, in-kernel resolve.
-//                           <., false> walks the flat sphere list (kernel 2; default below 64 spheres), <., true> the
-//                           two-level clustered list (kernel 3; default from 64 spheres on) with camera rays traced in
-//                           the primary pass (primary_trace: kernel 4 forces it at any spp)
+//   path_persistent_kernel  PATH mode v2, six instantiations <shading records in LDS?, clustered list?, flat-axis boxes?>:
+//                           persistent waves, two path slots per lane, per-XCD pixel queues, LDS accumulators, in-kernel
+//                           resolve.  <., false, false> walks the flat sphere list (kernel 2; default below 64 spheres),
+//                           <., true, .> the two-level clustered list (kernel 3; default from 64 spheres on) with camera
+//                           rays traced in the primary pass (primary_trace: kernel 4 forces it at any spp); <., true, true>
+//                           tests the cluster boxes without the axis they all share (scenes that stand on a plane)
 //   order_chunks_kernel     the next frame's chunk sequence from this frame's per-chunk costs (cost-ordered dequeue)
 //   arith_kernel            one operation per element: the arithmetic conformance probe of rtSelfTestArith
 //   (deinterleave_kernel, the multi-GPU frame assembly, lives in rtiow_multi.hip)
@@ -658,7 +659,8 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 #endif
 constexpr uint32_t kPoolWork = RTIOW_POOL_WORK;
 #ifndef RTIOW_LONG_FROM
-#define RTIOW_LONG_FROM 12
+#define RTIOW_LONG_FROM 20  // (round 2: 12; re-tuned for sixteen waves per CU: 8 / 12 / 16 / 20 / 32 -> cover frame 7.28 / 7.21 / 7.23 / 7.16 / 7.35 ms,
+                            // one eighth of it 1.26 / 1.26 / 1.26 / 1.24 / 1.25)
 #endif
 #ifndef RTIOW_LONG_WEIGHT
 #define RTIOW_LONG_WEIGHT 128
@@ -1896,25 +1898,23 @@ DI void primary_trace(const float4* slots, const uint32_t* idx_map, const float4
 }
 
 #ifndef RTIOW_SMALL_MAX_THREADS
-// largest group of the small-scene clustered variant.  (Tuning: 1024 = one group of sixteen waves, four per SIMD at 128
-// VGPRs: 84 registers spill to scratch and the cover frame takes 10.6 ms instead of 9.8, as in round 1.)
+// largest group of the small-scene clustered variants: two groups of 512 per CU are their sixteen waves (below)
 #define RTIOW_SMALL_MAX_THREADS 512
 #endif
 #ifndef RTIOW_SMALL_WAVES_PER_EU
-#define RTIOW_SMALL_WAVES_PER_EU 1  // (no constraint: the small-scene variants find their three waves per SIMD by themselves)
+#define RTIOW_SMALL_WAVES_PER_EU 1  // (this compilation: no constraint.  The Makefile's second pass over this file, which makes the
+                                    // small-scene clustered variants that are actually launched, sets 4: see the end of the file)
 #endif
 #ifndef RTIOW_ACCEL_MAX_THREADS
 #define RTIOW_ACCEL_MAX_THREADS 768
 #endif
-// The clustered kernel wants ~166 VGPRs: three waves per SIMD, i.e. at most 768 threads per CU, in one group or
-// several.  Small scenes run three 256-thread groups; a scene whose list leaves room for one copy only (C5's 4099
-// spheres: 95 KiB) runs ONE group of 768 (round 1 stopped at 512: two waves per SIMD).
+// The large-scene clustered variants want ~166 VGPRs: three waves per SIMD (<= 168), i.e. at most 768 threads per CU -- ONE
+// group of 768 for a scene whose lists leave room for one copy only (C5's 4099 spheres: 87 KiB; round 1 stopped at 512: two
+// waves per SIMD) -- held there by amdgpu_waves_per_eu.  The small-scene variants run FOUR waves per SIMD at 128 VGPRs, two
+// groups of 512 per CU (rounds 1-2: three waves, three groups of 256 at ~160 registers): see the end of the file.
+// tests/test_host_logic.py checks both budgets against the compiler's report.
 constexpr int kAccelMaxThreads = RTIOW_ACCEL_MAX_THREADS;
 
-// (Three waves per SIMD need <= 168 VGPRs, and the clustered kernel sits right at that edge.  The large-scene variant
-// is held there by amdgpu_waves_per_eu, which its 768-thread groups need.  The small-scene variant gets there by itself
-// (tests/test_host_logic.py checks the compiler's report) and is left alone: with the attribute the same source
-// schedules differently and the cover frame takes 4 % longer, 9.82 -> 10.25 ms.)
 // ---- The sparse loop at the end of a wave's frame (small-scene clustered kernel) -----------------------------------------------
 // Once the queues are dry and a wave is down to kSparseParMax paths, nothing of the main loop's refill is of use to it
 // any more -- no pool to fetch, no primary pass, no second slot: it gathers its paths in slot 0 once and ends its frame
@@ -2811,11 +2811,14 @@ __global__ __launch_bounds__(1024) void order_chunks_kernel(unsigned long long* 
 #endif  // RTIOW_TU_SMALL_CLUSTERED
 }  // namespace
 
-// The small-scene clustered kernel -- the default kernel of the headline frame -- is compiled in a second pass over this
-// file (Makefile: -DRTIOW_TU_SMALL_CLUSTERED, object rtiow_kernels_small.o) with the compiler's other instruction
-// scheduler, -mllvm -amdgpu-sched-strategy=iterative-ilp: same source, same registers (159, no spills), cover frame
-// 8.64 -> 8.40 ms, one eighth of it 1.46 -> 1.41 (interleaved A/B, tools/ab_bench.py).  The large-scene variant spills
-// under that scheduler (C5 1.16 -> 1.22 s) and the flat-list kernels lose 1 % to it, so they stay with the default.
+// The small-scene clustered kernels -- the default kernel of the headline frame -- are compiled in a second pass over this
+// file (Makefile: -DRTIOW_TU_SMALL_CLUSTERED, object rtiow_kernels_small.o) with a scheduler and a register budget of their
+// own.  Round 2: -mllvm -amdgpu-sched-strategy=iterative-ilp, 159 registers, three waves per SIMD (cover frame 8.64 -> 8.40
+// ms against the default scheduler).  Round 3: iterative-minreg brings the flat-axis variant to 136 registers; held to 128
+// (-DRTIOW_SMALL_WAVES_PER_EU=4) it spills 13 of them and runs FOUR waves per SIMD -- launch_path then finds two groups of
+// 512 threads per CU: cover frame 7.95 -> 7.19 ms, one eighth of it 1.33 -> 1.26 (interleaved A/B, tools/ab_bench.py;
+// iterative-minreg at three waves: 8.48).  The large-scene variants spill 115 registers at 128 and have no LDS for sixteen
+// waves' buffers, the flat-list kernels (95 registers) gain nothing: they stay with the default scheduler.
 #ifdef RTIOW_TU_SMALL_CLUSTERED
 PersistentKernelFn small_clustered_kernel(bool flat) {
     return flat ? path_persistent_kernel<true, true, true> : path_persistent_kernel<true, true, false>;
