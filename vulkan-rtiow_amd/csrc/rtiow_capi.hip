@@ -517,6 +517,16 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
                                                          : ctx->stats.segments * ctx->stats.n_spheres;
         for (int k = 0; k < 8; ++k) ctx->stats.debug[k] = ctx->h_counters->debug[k];
 #ifdef RTIOW_DEBUG_TIMELINE
+        if (const char* path = getenv("RTIOW_DEBUG_WAVELOG")) {  // one line per wave: see Counters::tl_wave
+            if (FILE* f = fopen(path, "w")) {
+                for (int wv = 0; wv < 8192; ++wv) {
+                    const unsigned int* r = ctx->h_counters->tl_wave[wv];
+                    if (r[2] == 0u) continue;
+                    fprintf(f, "%d %u %u %u %u %u %u %u %u\n", wv, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+                }
+                fclose(f);
+            }
+        }
         if (getenv("RTIOW_DEBUG_HIST")) {
             const rtiow::Counters& c = *ctx->h_counters;
             static const char* names[3] = {"dry   ", "sparse", "done  "};

@@ -46,6 +46,12 @@ struct Counters {
     unsigned int tl_live_at_dry_hist[9];    // waves by their live paths when they found the queues dry (bins of 16)
     unsigned int tl_late_dry_live_hist[9];  // the same for the waves that ran dry more than 100 us after the first one
     unsigned long long not_first_dry;       // ~(earliest dry stamp)
+#ifdef RTIOW_DEBUG_TIMELINE
+    // one record per wave (RTIOW_DEBUG_WAVELOG=file dumps them): dry, first sparse iteration, end (100 MHz ticks from the first
+    // wave's start), iterations after dry, sparse ones among them, live paths at dry, deepest path finished after dry, when the
+    // last path of 40+ segments finished
+    unsigned int tl_wave[8192][8];
+#endif
 };
 
 // Device-side shading record of one sphere (32 B), built by rtSetScene from RtSphere + RtMaterial.

@@ -666,7 +666,11 @@ constexpr uint32_t kPoolWork = RTIOW_POOL_WORK;
 #define RTIOW_LONG_WEIGHT 128
 #endif
 constexpr uint32_t kLongFrom = RTIOW_LONG_FROM, kLongWeight = RTIOW_LONG_WEIGHT;  // cost of a path of more segments than kLongFrom, for the chunk order
-constexpr int kSlots = 2;           // path slots per lane
+#ifndef RTIOW_SLOTS
+#define RTIOW_SLOTS 2  // (-DRTIOW_SLOTS=1: ablation only -- half the paths in flight)
+#endif
+constexpr int kSlots = RTIOW_SLOTS;  // path slots per lane
+static_assert(kSlots == 1 || kSlots == 2, "the work lists encode the path slot in one bit");
 constexpr uint32_t kBlockSph = 32;  // spheres per candidate word
 #ifndef RTIOW_SPARSE_MAX
 #define RTIOW_SPARSE_MAX 16
@@ -1054,13 +1058,18 @@ DI void load_box(const float4* bounds, const PathArgs& a, uint32_t i, float4& mi
 template <int R>
 DI void fetch_item_ray(const Slot (&sl)[R], uint32_t item, float& ox, float& oy, float& oz, float& dx, float& dy,
                        float& dz) {
-    static_assert(R == 2, "the work lists encode the path slot in one bit");
+    static_assert(R == 1 || R == 2, "the work lists encode the path slot in one bit");
     const int src = static_cast<int>(item & 63u);
     const bool second = (item & 64u) != 0u;
     const float ox0 = __shfl(sl[0].p.o.x, src), oy0 = __shfl(sl[0].p.o.y, src), oz0 = __shfl(sl[0].p.o.z, src);
     const float dx0 = __shfl(sl[0].p.du.x, src), dy0 = __shfl(sl[0].p.du.y, src), dz0 = __shfl(sl[0].p.du.z, src);
-    const float ox1 = __shfl(sl[1].p.o.x, src), oy1 = __shfl(sl[1].p.o.y, src), oz1 = __shfl(sl[1].p.o.z, src);
-    const float dx1 = __shfl(sl[1].p.du.x, src), dy1 = __shfl(sl[1].p.du.y, src), dz1 = __shfl(sl[1].p.du.z, src);
+    if constexpr (R == 1) {
+        ox = ox0; oy = oy0; oz = oz0;
+        dx = dx0; dy = dy0; dz = dz0;
+        return;
+    }
+    const float ox1 = __shfl(sl[R - 1].p.o.x, src), oy1 = __shfl(sl[R - 1].p.o.y, src), oz1 = __shfl(sl[R - 1].p.o.z, src);
+    const float dx1 = __shfl(sl[R - 1].p.du.x, src), dy1 = __shfl(sl[R - 1].p.du.y, src), dz1 = __shfl(sl[R - 1].p.du.z, src);
     ox = second ? ox1 : ox0;
     oy = second ? oy1 : oy0;
     oz = second ? oz1 : oz0;
@@ -1605,17 +1614,178 @@ DI void trace_sparse_parallel(const float4* slots, const uint32_t* idx_map, cons
     }
 }
 
+// ---- The same for at most kSparseBatchMax paths, with the LDS round trips taken together --------------------------------------
+// trace_sparse_parallel takes a path through the boxes one at a time -- read, test, ballot, write the item, and only then
+// the next read -- and through the work list 64 lanes at a time: with P paths on 32 boxes that is P / 2 + P / 3 dependent
+// LDS round trips of a few hundred cycles each, and at the end of a frame, where a wave is alone on its SIMD, those are what
+// an iteration costs (tools/sparse_latency.py: 2.0 us for 3 paths, 3.7 for a dozen, 6.3 for 32 in a lone wave).  Here a lane takes FOUR boxes per trip --
+// their reads issued together, one prefix sum over the lanes' counts places all the items -- and FOUR list entries per
+// trip, sphere, ray and original index of each asked for at once.  Same tests, same key, same minimum.
+// One level of boxes only (the small-scene kernels, whose sparse loop is the one place that calls it).
+#ifndef RTIOW_SPARSE_BATCH_MIN
+#define RTIOW_SPARSE_BATCH_MIN 1
+#endif
+constexpr uint32_t kSparseBatchMax = 16;  // paths
+// (With one to four paths a trip's four boxes and four list entries are half padding, and tools/sparse_latency.py -- every
+// wave of the chip with P mirror paths -- has the batched form 6 % slower there and 8-19 % faster from six paths on; on real
+// frames thresholds of 1 / 3 / 5 / 7 paths are indistinguishable -- one eighth of the cover frame 1.209 / 1.239 / 1.216 /
+// 1.219 ms against 1.233 without, a 1-spp frame 0.439 / 0.445 / 0.443 / 0.452 against 0.456 -- so there is no threshold.)
+constexpr uint32_t kSparseBatchMin = RTIOW_SPARSE_BATCH_MIN;
+
+// sphere s (original index orig, list slot `slot`) against a ray: examine_keyed with its operands already loaded
+DI void examine_loaded(const float4& s, uint32_t orig, uint32_t slot, const SparseRay& r, unsigned long long& key) {
+    const float ocx = r.ox - s.x, ocy = r.oy - s.y, ocz = r.oz - s.z;
+    const float hb = fma_(ocz, r.dz, fma_(ocy, r.dy, ocx * r.dx));
+    const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
+    const float disc = fma_(hb, hb, -cc);
+    if (__builtin_signbit(disc) || disc != disc) return;
+    const float sq = __builtin_sqrtf(disc);
+    float root = -hb - sq;
+    root = root > kTMin ? root : -hb + sq;
+    if (!(root > kTMin)) return;
+    const unsigned long long k2 = (static_cast<unsigned long long>(__float_as_uint(root)) << 32) | (orig << 16) | slot;
+    key = k2 < key ? k2 : key;
+}
+
+// consumes `count` (path, cluster) items: sixteen lanes per item, one member each, four items per lane and trip
+DI void sparse_members4(const float4* slots, const uint32_t* idx_map, const PathArgs& a, const uint16_t* items,
+                        uint32_t count, const float* rays, unsigned long long* keys, uint32_t& n_tests) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total = count * kClusterSize;
+    for (uint32_t q0 = 0; q0 < total; q0 += 256u) {
+        uint32_t item[4];
+        bool valid[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t q = q0 + u * 64u + lane;
+            valid[u] = q < total;
+            item[u] = valid[u] ? items[q / kClusterSize] : 0u;
+        }
+        float4 s[4];
+        uint32_t orig[4], slot[4];
+        SparseRay ray[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            slot[u] = a.n_large_slots + (item[u] >> 5) * kClusterStride + (lane & (kClusterSize - 1u));
+            ray[u] = load_sparse_ray(rays, item[u] & (kSparseParMax - 1u));
+            s[u] = slots[slot[u]];
+            orig[u] = idx_map[slot[u]];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            if (valid[u]) {
+                unsigned long long k2 = ~0ull;
+                examine_loaded(s[u], orig[u], slot[u], ray[u], k2);
+                ++n_tests;
+                if (k2 != ~0ull) atomicMin(&keys[item[u] & (kSparseParMax - 1u)], k2);
+            }
+        }
+    }
+}
+
+template <bool FLAT>
+DI void trace_sparse_batched(const float4* slots, const uint32_t* idx_map, const float4* bounds, const PathArgs& a,
+                             uint16_t* items, unsigned long long* results, Slot& sl, float& best, int& best_i,
+                             uint32_t& best_o, uint32_t& n_tests) {
+    static_assert(kSparseBatchMax <= kSparseParMax && 4u * 64u <= kItemCap, "items carry the path in five bits; a trip's items fit the list");
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long* keys = results;
+    float* rays = reinterpret_cast<float*>(results + kSparseParMax);
+    const unsigned long long live = __ballot(sl.active);
+    const uint32_t n_live = static_cast<uint32_t>(__popcll(live));
+    const uint32_t pidx = lane_rank(live);
+    if (sl.active) {
+        const Path& p = sl.p;
+        float2* dst = reinterpret_cast<float2*>(rays + pidx * 6u);
+        dst[0] = make_float2(p.o.x, p.o.y);
+        dst[1] = make_float2(p.o.z, p.du.x);
+        dst[2] = make_float2(p.du.y, p.du.z);
+    }
+    if (lane < n_live) keys[lane] = ~0ull;
+    // (a wave's LDS operations are performed in order: rays and keys are in place for what follows)
+    uint32_t shift = 6u;  // log2 of the lanes a path gets
+    while ((n_live << shift) > 64u) --shift;
+    const uint32_t gsz = 1u << shift;
+    const uint32_t p = lane >> shift, j0 = lane & (gsz - 1u);
+    const bool mine = p < n_live;
+    const SparseRay ray = load_sparse_ray(rays, mine ? p : 0u);
+    const float ix = slab_rcp(ray.dx), iy = slab_rcp(ray.dy), iz = slab_rcp(ray.dz);
+    const float ax = -ray.ox * ix, ay = -ray.oy * iy, az = -ray.oz * iz;
+    const float qx = ray.ox - a.ccenter[0], qy = ray.oy - a.ccenter[1], qz = ray.oz - a.ccenter[2];
+    const bool outside = !(fma_(qz, qz, fma_(qy, qy, qx * qx)) <= a.crmax2);
+    [[maybe_unused]] FlatRay f{};
+    if (FLAT) f = flat_ray(a, ix, iy, iz, ax, ay, az);
+    // the large spheres, exactly
+    for (uint32_t base = 0; base < a.n_large; base += gsz) {
+        const uint32_t j = base + j0;
+        if (mine && j < a.n_large) {
+            unsigned long long k2 = ~0ull;
+            examine_keyed(slots, idx_map, j, ray.ox, ray.oy, ray.oz, ray.dx, ray.dy, ray.dz, k2);
+            ++n_tests;
+            if (k2 != ~0ull) atomicMin(&keys[p], k2);
+        }
+    }
+    // the cluster boxes, four per lane and trip
+    uint32_t pending = 0u;
+    for (uint32_t base = 0; base < a.n_clusters; base += 4u * gsz) {
+        if (pending + 256u > kItemCap) {
+            sparse_members4(slots, idx_map, a, items, pending, rays, keys, n_tests);
+            pending = 0u;
+        }
+        uint32_t b[4];
+        bool valid[4];
+        float4 mid[4], half[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            b[u] = base + u * gsz + j0;
+            valid[u] = mine && b[u] < a.n_clusters;
+            const uint32_t i = valid[u] ? b[u] : 0u;
+            if (FLAT) {
+                mid[u] = half[u] = bounds[i];
+            } else {
+                mid[u] = bounds[2u * i];
+                half[u] = bounds[2u * i + 1u];
+            }
+        }
+        uint32_t mask = 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const float gap = FLAT ? slab_gap_flat(mid[u], f.ia, f.ib, f.oa, f.ob, f.tn_f, f.tf_f)
+                                   : slab_gap(mid[u], half[u], ix, iy, iz, ax, ay, az);
+            if (valid[u]) {
+                ++n_tests;
+                if (outside || !__builtin_signbit(gap)) mask |= 1u << u;
+            }
+        }
+        const uint32_t cnt = static_cast<uint32_t>(__builtin_popcount(mask));
+        const uint32_t incl = wave_inclusive_sum(cnt);
+        uint32_t pos = pending + incl - cnt;
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u)
+            if ((mask >> u) & 1u) items[pos++] = static_cast<uint16_t>(p | (b[u] << 5));
+        pending += __builtin_amdgcn_readlane(incl, 63);
+    }
+    sparse_members4(slots, idx_map, a, items, pending, rays, keys, n_tests);
+    const unsigned long long k = sl.active ? keys[pidx] : ~0ull;
+    const bool hit = k != ~0ull;
+    best = hit ? __uint_as_float(static_cast<uint32_t>(k >> 32)) : __builtin_inff();
+    best_i = hit ? static_cast<int>(k & 0xFFFFu) : -1;
+    best_o = static_cast<uint32_t>(k >> 16) & 0xFFFFu;
+}
+
 // Moves the live paths of slot 1 into idle lanes of slot 0 through a per-wave LDS scratch (64-byte
 // records).  Only for a wave with at most 32 live paths: slot 0 then has room for all of them.
 // Which lane carries a path is immaterial: its pixel's accumulator is addressed by `entry`.
-DI void compact_to_slot0(Slot (&sl)[2], uint32_t* scratch) {
-    const unsigned long long m1 = __ballot(sl[1].active);
+template <int R>
+DI void compact_to_slot0(Slot (&sl)[R], uint32_t* scratch) {
+    if constexpr (R == 1) return;
+    const unsigned long long m1 = __ballot(sl[R - 1].active);
     if (m1 == 0ull) return;
     const uint32_t n1 = static_cast<uint32_t>(__popcll(m1));
     const unsigned long long idle0 = __ballot(!sl[0].active);
     float* recs = reinterpret_cast<float*>(scratch);
-    if (sl[1].active) {
-        Slot& q = sl[1];
+    if (sl[R - 1].active) {
+        Slot& q = sl[R - 1];
         float* rec = recs + lane_rank(m1) * 16u;
         rec[0] = q.p.o.x; rec[1] = q.p.o.y; rec[2] = q.p.o.z;
         rec[3] = q.p.du.x; rec[4] = q.p.du.y; rec[5] = q.p.du.z;
@@ -1928,6 +2098,9 @@ constexpr int kAccelMaxThreads = RTIOW_ACCEL_MAX_THREADS;
 #ifndef RTIOW_TAIL_LOOP
 #define RTIOW_TAIL_LOOP 1  // (-DRTIOW_TAIL_LOOP=0: A/B only)
 #endif
+#ifndef RTIOW_SPARSE_BATCHED
+#define RTIOW_SPARSE_BATCHED 1  // (-DRTIOW_SPARSE_BATCHED=0: A/B only)
+#endif
 // FLAT (clustered kernels): the scene's cluster boxes share one interval along a.flat_axis, and the lock-step box tests
 // leave that axis out (slab_gap_flat).
 template <bool SHADE_LDS, bool ACCEL, bool FLAT = false>
@@ -2015,8 +2188,13 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     if (lane == 0u) atomicMax(&a.counters->not_t0, ~tl_start);
     unsigned long long tl_dry = 0ull, tl_sparse = 0ull;
     uint32_t tl_tail_iters = 0u, tl_sparse_iters = 0u, tl_sparse_paths = 0u, tl_starved = 0u, tl_live_at_dry = ~0u;
+    uint32_t tl_deepest = 0u;            // (per lane) deepest path finished after dry
+    unsigned long long tl_deep_end = 0ull;  // (per lane) when the last path of 40+ segments finished
 #endif
     uint32_t n_paths = 0, n_segments = 0, n_tests = 0;
+#ifdef RTIOW_DEBUG_WAVE_POOLS
+    uint32_t dbg_pools_drawn = 0u;
+#endif
     [[maybe_unused]] uint32_t dbg_slow_trips = 0, dbg_cands = 0, dbg_iters = 0, dbg_sparse = 0;
     [[maybe_unused]] unsigned long long dbg_t_refill = 0, dbg_t_trace = 0, dbg_t_slow = 0, dbg_t_shade = 0;
     [[maybe_unused]] unsigned long long dbg_pass[6] = {0, 0, 0, 0, 0, 0};
@@ -2070,6 +2248,10 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         bool completed = false;
         bool line_full = false;  // this lane's pixel was the last of a line buffer
         if (finished) {
+#ifdef RTIOW_DEBUG_TIMELINE
+            if (tl_dry != 0ull && q.depth + 1u > tl_deepest) tl_deepest = q.depth + 1u;
+            if (q.depth + 1u >= 40u) tl_deep_end = wall_clock64();
+#endif
             q.active = false;
             unsigned long long* acc = lds_acc + q.entry * kAccWords;
             // low half: samples done; high half: the segments they took (<= 65535 each, <= 65536 samples)
@@ -2148,6 +2330,10 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                         // on, so the 4-byte stores that complete a 128-byte line of the frame all come from one L2
                         // and merge there.  An XCD whose queue is dry steals from the next one.
                         bool fetched = false;
+#ifdef RTIOW_DEBUG_WAVE_POOLS  // (tools/sparse_latency.py: a wave draws this many pools and no more)
+                        if (dbg_pools_drawn >= RTIOW_DEBUG_WAVE_POOLS) steal = 8u;
+                        ++dbg_pools_drawn;
+#endif
                         while (steal < 8u && !fetched) {
                             const uint32_t xq = (xcc + steal) & 7u;
                             const uint32_t vsize = ((n_chunks + 7u - xq) / 8u) * kChunkPix;  // virtual pixels of queue xq
@@ -2283,7 +2469,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             float4* scratch4 = reinterpret_cast<float4*>(lds_results);
             auto record = [&](uint32_t k) { return k < g.pass_keep ? lds_pbuf + 3u * k : scratch4 + 3u * (k - g.pass_keep); };
             for (; !SHADE_LDS || g.use_pass != 0u;) {  // (large scenes: always, see below)
-                const unsigned long long idle0 = __ballot(!sl[0].active), idle1 = __ballot(!sl[1].active);
+                const unsigned long long idle0 = __ballot(!sl[0].active), idle1 = kSlots > 1 ? __ballot(!sl[kSlots - 1].active) : 0ull;
                 const uint32_t n_idle0 = static_cast<uint32_t>(__popcll(idle0));
                 const uint32_t n_idle = n_idle0 + static_cast<uint32_t>(__popcll(idle1));
                 if (n_idle == 0u) break;
@@ -2292,7 +2478,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     // idle slots wait until there are enough of them -- unless the wave has nothing else to do)
                     // (Only in the large-scene variant: small scenes always have room for their 32 records, and the mere
                     // presence of this test cost the cover frame 3 % -- 8.63 -> 8.88 ms -- through the code around it.)
-                    if (!SHADE_LDS && n_idle < g.pass_min_idle && __ballot(sl[0].active || sl[1].active) != 0ull) break;
+                    if (!SHADE_LDS && n_idle < g.pass_min_idle && __ballot(sl[0].active || sl[kSlots - 1].active) != 0ull) break;
                     Slot ps;
                     ps.active = false;
                     ps.pix = ps.entry = ps.line = ps.depth = 0u;
@@ -2366,7 +2552,9 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 // the last `give` records go to the idle slots, numbered across both slots
                 // (a wave's LDS operations are performed in order: the records are there)
                 const uint32_t give = pass_n < n_idle ? pass_n : n_idle;
-                const uint32_t my_idx[kSlots] = {lane_rank(idle0), n_idle0 + lane_rank(idle1)};
+                uint32_t my_idx[kSlots];
+                my_idx[0] = lane_rank(idle0);
+                if (kSlots > 1) my_idx[kSlots - 1] = n_idle0 + lane_rank(idle1);
 #pragma unroll
                 for (int r = 0; r < kSlots; ++r) {
                     Slot& q = sl[r];
@@ -2395,14 +2583,18 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 // stages -- for the pass to pay even with a wide cone.)  The idle slots are numbered across both slots,
                 // lane k generates the camera path of number k -- ONE pass of the camera code instead of one per slot
                 // -- and leaves it in the wave's LDS scratch, where the lane that owns slot number k picks it up.
-                const unsigned long long idle0 = __ballot(!sl[0].active), idle1 = __ballot(!sl[1].active);
+                const unsigned long long idle0 = __ballot(!sl[0].active), idle1 = kSlots > 1 ? __ballot(!sl[kSlots - 1].active) : 0ull;
                 const uint32_t n_idle0 = static_cast<uint32_t>(__popcll(idle0));
                 const uint32_t n_idle = n_idle0 + static_cast<uint32_t>(__popcll(idle1));
                 uint32_t left = n_idle;
                 while (left != 0u) {  // (at most two trips: 64 lanes per trip)
                     const uint32_t done = n_idle - left;
-                    const uint32_t my_idx[kSlots] = {lane_rank(idle0) - done, n_idle0 + lane_rank(idle1) - done};  // (unsigned: < 64 = this trip)
-                    bool got[kSlots] = {false, false};
+                    uint32_t my_idx[kSlots];  // (unsigned: < 64 = this trip)
+                    my_idx[0] = lane_rank(idle0) - done;
+                    if (kSlots > 1) my_idx[kSlots - 1] = n_idle0 + lane_rank(idle1) - done;
+                    bool got[kSlots];
+#pragma unroll
+                    for (int r = 0; r < kSlots; ++r) got[r] = false;
                     uint32_t gen_pix = 0u, gen_s = 0u;
                     const uint32_t want = left < 64u ? left : 64u;
                     const uint32_t granted = hand_out(want, [&](uint32_t first, uint32_t n, uint32_t pix, uint32_t entry, uint32_t s0) {
@@ -2447,9 +2639,9 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     left -= granted;
                 }
             }
-            any_active = sl[0].active || sl[1].active;
+            any_active = sl[0].active || sl[kSlots - 1].active;
         } else {
-            const unsigned long long idle0 = __ballot(!sl[0].active), idle1 = __ballot(!sl[1].active);
+            const unsigned long long idle0 = __ballot(!sl[0].active), idle1 = kSlots > 1 ? __ballot(!sl[kSlots - 1].active) : 0ull;
 #pragma unroll
             for (int r = 0; r < kSlots; ++r) {  // slot by slot
                 Slot& q = sl[r];
@@ -2484,7 +2676,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
 #ifdef RTIOW_DEBUG_TIMELINE
         if (tl_dry != 0ull) ++tl_tail_iters;
         if (tl_dry != 0ull && tl_live_at_dry == ~0u) {
-            tl_live_at_dry = static_cast<uint32_t>(__popcll(__ballot(sl[0].active)) + __popcll(__ballot(sl[1].active))) + pass_n;
+            tl_live_at_dry = static_cast<uint32_t>(__popcll(__ballot(sl[0].active)) + (kSlots > 1 ? __popcll(__ballot(sl[kSlots - 1].active)) : 0)) + pass_n;
             if (lane == 0u) atomicMax(&a.counters->not_first_dry, ~tl_dry);
         }
 #endif
@@ -2591,6 +2783,11 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 float best[kSlots];
                 int best_i[kSlots];
                 uint32_t best_o[kSlots];
+#if RTIOW_SPARSE_BATCHED
+                if (SHADE_LDS && live >= kSparseBatchMin && live <= kSparseBatchMax) {  // (small scenes: one level of boxes)
+                    trace_sparse_batched<FLAT>(lds_spheres, lds_cidx, lds_cbounds, a, lds_items, lds_results, sl[0], best[0], best_i[0], best_o[0], n_tests);
+                } else
+#endif
                 trace_sparse_parallel<kSlots, !SHADE_LDS, FLAT>(lds_spheres, lds_cidx, lds_cbounds, a, lds_items, lds_results, sl, best, best_i,
                                                                 best_o, n_tests);
                 float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0;
@@ -2605,9 +2802,24 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     }
 
 #ifdef RTIOW_DEBUG_TIMELINE
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t d2 = __shfl_down(tl_deepest, off);
+        tl_deepest = d2 > tl_deepest ? d2 : tl_deepest;
+        const unsigned long long e2 = __shfl_down(tl_deep_end, off);
+        tl_deep_end = e2 > tl_deep_end ? e2 : tl_deep_end;
+    }
     if (lane == 0u) {
         const unsigned long long t0w = ~__hip_atomic_load(&a.counters->not_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long stamps[3] = {tl_dry, tl_sparse, static_cast<unsigned long long>(wall_clock64())};
+        {
+            const uint32_t wv = blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u;
+            if (wv < 8192u) {
+                unsigned int* rec = a.counters->tl_wave[wv];
+                auto rel = [&](unsigned long long t) { return t == 0ull ? 0u : static_cast<unsigned int>(t > t0w ? t - t0w : 1ull); };
+                rec[0] = rel(tl_dry); rec[1] = rel(tl_sparse); rec[2] = rel(stamps[2]);
+                rec[3] = tl_tail_iters; rec[4] = tl_sparse_iters; rec[5] = tl_live_at_dry; rec[6] = tl_deepest; rec[7] = rel(tl_deep_end);
+            }
+        }
         for (int k = 0; k < 3; ++k) {
             if (stamps[k] == 0ull) continue;
             const unsigned long long b = (stamps[k] > t0w ? stamps[k] - t0w : 0ull) / 5000ull;  // 50 us bins
