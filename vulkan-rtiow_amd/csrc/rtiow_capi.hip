@@ -526,6 +526,13 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
                 }
                 fclose(f);
             }
+            static const char* held[5] = {"1-2", "3-4", "5-8", "9-16", "17-32"};
+            for (int k = 0; k < 5; ++k) {
+                const unsigned long long* b = ctx->h_counters->tl_bucket[k];
+                if (b[0] != 0ull)
+                    fprintf(stderr, "sparse iterations with %s paths: %llu, %.2f us each (trace %.0f + shade %.0f shader cycles)\n", held[k], b[0],
+                            b[1] * 0.01 / b[0], double(b[2]) / b[0], double(b[3]) / b[0]);
+            }
         }
         if (getenv("RTIOW_DEBUG_HIST")) {
             const rtiow::Counters& c = *ctx->h_counters;
