@@ -121,12 +121,13 @@ def test_default_kernel_choice(gpu_ctx):
     assert gpu_ctx.last_kernel() == V.KERNEL_PERSISTENT
 
 
-@pytest.mark.parametrize("n", [40, 330, 1700])
+@pytest.mark.parametrize("n", [40, 330, 500, 1700])
 def test_rays_from_outside_the_box_range(gpu_ctx, oracle, n):
     """A tight knot of spheres on a huge ground, wide camera: most bounces start on the ground far
     outside the range the cluster boxes are inflated for (2 scene diagonals) and must walk every
-    cluster; with 330 spheres a wave's pooled work list overflows and each lane walks its own; with 1700
-    the scene has super-clusters and it is their list that overflows."""
+    cluster; with 330 spheres a wave's pooled work list overflows and each lane walks its own; 500 is about the largest
+    scene of the small-scene kernel (32 clusters: the batched sparse trace of a wave with 16 paths fills its work list to the
+    last entry); with 1700 the scene has super-clusters and it is their list that overflows."""
     rng = np.random.default_rng(77 + n)
     sph = np.zeros(n + 1, V.SPHERE_DTYPE)
     mat = np.zeros(n + 1, V.MATERIAL_DTYPE)
