@@ -22,7 +22,9 @@ with V.Context(0) as ctx:
 r = np.loadtxt(log, dtype=np.int64)
 us = lambda t: t * 0.01
 dry, sparse, end, tail_it, sp_it, live_dry, deepest, deep_end = (r[:, k] for k in range(1, 9))
-adopted, gave, live_dry = (live_dry >> 12) & 0xFFF, live_dry >> 24, live_dry & 0xFFF  # (merge builds; 0 otherwise)
+sparse_paths, live_dry = live_dry >> 8, live_dry & 0xFF  # (paths summed over the wave's sparse iterations)
+adopted = gave = np.zeros_like(live_dry)
+mean_p = sparse_paths / np.maximum(sp_it, 1)
 print(f"waves {len(r)}; dry: first {us(dry[dry > 0].min()):.0f} median {us(np.median(dry[dry > 0])):.0f} last {us(dry.max()):.0f} us; "
       f"end: median {us(np.median(end)):.0f} p90 {us(np.percentile(end, 90)):.0f} p99 {us(np.percentile(end, 99)):.0f} last {us(end.max()):.0f} us")
 print(f"iterations after dry: mean {tail_it.mean():.1f} (sparse {sp_it.mean():.1f}); live at dry: mean {live_dry[live_dry < 1000].mean():.0f}")
@@ -41,9 +43,11 @@ if adopted.any() or gave.any():
             print(f"waves that {name}: {m.sum()}, sparse iterations {sp_it[m].mean():.1f}, {per_it[m].mean():.2f} us each, end median {us(np.median(end[m])):.0f} "
                   f"last {us(end[m].max()):.0f}; paths adopted {adopted[m].mean():.1f} given {gave[m].mean():.1f}")
 order = np.argsort(-end)
-print("the last waves:  wave   dry  sparse    end | iters after dry (sparse) | live at dry | deepest after dry | last 40+ path ended")
+print("the last waves:  wave   dry  sparse    end | iters after dry (sparse) | live at dry | deepest after dry | last 40+ path ended | mean paths per sparse iteration")
 for k in order[:25]:
-    print(f"               {r[k,0]:5d} {us(dry[k]):5.0f} {us(sparse[k]):6.0f} {us(end[k]):6.0f} | {tail_it[k]:4d} ({sp_it[k]:3d}) | {live_dry[k]:4d} +{adopted[k]:<3d} | {deepest[k]:3d} | {us(deep_end[k]):6.0f}")
+    print(f"               {r[k,0]:5d} {us(dry[k]):5.0f} {us(sparse[k]):6.0f} {us(end[k]):6.0f} | {tail_it[k]:4d} ({sp_it[k]:3d}) | {live_dry[k]:4d} +{adopted[k]:<3d} | {deepest[k]:3d} | {us(deep_end[k]):6.0f} | {mean_p[k]:5.1f}")
 late = end > np.percentile(end, 90)
+print(f"mean paths per sparse iteration: all waves {mean_p[sp_it > 0].mean():.1f}, the last tenth {mean_p[late].mean():.1f}, the last hundredth {mean_p[end > np.percentile(end, 99)].mean():.1f}; "
+      f"correlation of a wave's end with its mean paths {np.corrcoef(end[sp_it > 0], mean_p[sp_it > 0])[0, 1]:.2f}, with its sparse iterations {np.corrcoef(end[sp_it > 0], sp_it[sp_it > 0])[0, 1]:.2f}")
 print(f"the last tenth of the waves: deepest path after dry: mean {deepest[late].mean():.1f}, share with a 40+ path {np.mean(deepest[late] >= 40):.2f}; "
       f"all waves: {deepest.mean():.1f}, {np.mean(deepest >= 40):.2f}")

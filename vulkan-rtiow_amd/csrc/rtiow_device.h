@@ -48,8 +48,8 @@ struct Counters {
     unsigned long long not_first_dry;       // ~(earliest dry stamp)
 #ifdef RTIOW_DEBUG_TIMELINE
     // one record per wave (RTIOW_DEBUG_WAVELOG=file dumps them): dry, first sparse iteration, end (100 MHz ticks from the first
-    // wave's start), iterations after dry, sparse ones among them, live paths at dry, deepest path finished after dry, when the
-    // last path of 40+ segments finished
+    // wave's start), iterations after dry, sparse ones among them, live paths at dry | paths summed over its sparse iterations << 8,
+    // deepest path finished after dry, when the last path of 40+ segments finished
     unsigned int tl_wave[8192][8];
     unsigned long long tl_bucket[5][4];  // sparse iterations by paths held (1-2, 3-4, 5-8, 9-16, 17-32): count, ticks, trace cycles, shade cycles
 #endif

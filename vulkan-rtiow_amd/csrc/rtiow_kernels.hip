@@ -2817,7 +2817,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 unsigned int* rec = a.counters->tl_wave[wv];
                 auto rel = [&](unsigned long long t) { return t == 0ull ? 0u : static_cast<unsigned int>(t > t0w ? t - t0w : 1ull); };
                 rec[0] = rel(tl_dry); rec[1] = rel(tl_sparse); rec[2] = rel(stamps[2]);
-                rec[3] = tl_tail_iters; rec[4] = tl_sparse_iters; rec[5] = tl_live_at_dry; rec[6] = tl_deepest; rec[7] = rel(tl_deep_end);
+                rec[3] = tl_tail_iters; rec[4] = tl_sparse_iters; rec[5] = (tl_live_at_dry & 0xFFu) | (tl_sparse_paths << 8); rec[6] = tl_deepest; rec[7] = rel(tl_deep_end);
             }
         }
         for (int k = 0; k < 3; ++k) {
