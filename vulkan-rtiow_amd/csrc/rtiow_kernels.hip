@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void ch_kernel_tiles(ChArgs a) {
 // stay in registers from row to row.
 struct ChConst {  // per-frame constants of raytrace06.comp:53-56, 21-27, by the shader's own expressions
     float hx, vy, llc_x, llc_y, dz, zz, oz_dz, oc_x, oc_y, qc;
+    float qb;  // LEAN kernels: 2 * gdot(oc, dir), the same for every pixel (see ch_pixel)
 };
 DI ChConst ch_constants(const RtUbo5& ubo) {
     const f3 origin = mk(0.0f, 0.0f, 0.0f);
@@ -224,6 +225,7 @@ DI ChConst ch_constants(const RtUbo5& ubo) {
     k.zz = k.dz * k.dz;
     k.oz_dz = oc.z * k.dz;
     k.qc = gdot(oc, oc) - radius * radius;
+    k.qb = 2.0f * k.oz_dz;
     return k;
 }
 
@@ -273,7 +275,12 @@ DI uint32_t ch_pixel(uint32_t mode, const ChConst& k, float dx, float xx, float 
     auto sqrt_ = [](float x) { return LEAN ? ch_sqrt(x) : __builtin_sqrtf(x); };
     auto div_ = [](float a, float b) { return LEAN ? ch_div(a, b) : a / b; };
     const float qa = (xx + yy) + k.zz;             // gdot(dir, dir)
-    const float qb = 2.0f * ((ox + oy) + k.oz_dz);   // 2 * gdot(oc, dir)
+    // 2 * gdot(oc, dir).  oc = origin - centre = (+0, +0, 1) by the shader's constants, so oc.x * dir.x and oc.y * dir.y are zeros
+    // of either sign for the finite dir.x, dir.y of a frame with finite UBO values, their sum is a zero, and a zero plus
+    // oc.z * dir.z = -focalLength is that number exactly when it is not itself zero: under the LEAN kernels' precondition
+    // (|focalLength| in [2^-20, 2^20]) the three-term sum IS k.oz_dz for every pixel, bit for bit, and is taken from the frame
+    // constants -- five instructions and two LDS operands per pixel less.  (The full kernels, launched for any other UBO, add it up.)
+    const float qb = LEAN ? k.qb : 2.0f * ((ox + oy) + k.oz_dz);
     const float disc = qb * qb - 4 * qa * k.qc;
     f3 col;
     bool shaded = false;
