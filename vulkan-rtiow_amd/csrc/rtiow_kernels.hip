@@ -1655,7 +1655,7 @@ DI void examine_loaded(const float4& s, uint32_t orig, uint32_t slot, const Spar
 }
 
 // consumes `count` (path, cluster) items: sixteen lanes per item, one member each, four items per lane and trip
-DI void sparse_members4(const float4* slots, const uint32_t* idx_map, const PathArgs& a, const uint16_t* items,
+[[maybe_unused]] DI void sparse_members4(const float4* slots, const uint32_t* idx_map, const PathArgs& a, const uint16_t* items,
                         uint32_t count, const float* rays, unsigned long long* keys, uint32_t& n_tests) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = count * kClusterSize;
