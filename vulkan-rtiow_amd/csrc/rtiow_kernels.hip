@@ -234,11 +234,17 @@ DI ChConst ch_constants(const RtUbo5& ubo) {
 // 0 the clamp gives 0.5 -> 0 and the conversion 0; inside [0, 1] the two expressions are the same float; above 1 the clamp
 // gives 255.5 -> 255 and the conversion something >= 255, which the integer minimum brings back.  (Written as asm: a C cast
 // of an out-of-range float is undefined, the instruction is not.)
+// BOUNDED (the lean kernels): the caller's x is known to lie in [-2^-10, 1 + 2^-10] and the minimum is dropped -- x * 255 + 0.5 is
+// then below 256.  That holds for every colour the shaders make from a moderate UBO: normalize() divides a component by the
+// correctly rounded root of a sum of squares that contains its own square, so a unit vector's component is 1 + a few ulps at
+// most in magnitude; 0.5 * (n + 1) and the sky's (1 - t) + c * t with t = 0.5 * (unit.y + 1), c <= 1 stay within a few ulps
+// of [0, 1]; raytrace05's red is (1, 0, 0).
+template <bool BOUNDED = false>
 DI uint32_t ch_unorm8(float x) {
     const float y = x * 255.0f + 0.5f;
     uint32_t q;
     asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(y));
-    return q < 255u ? q : 255u;
+    return BOUNDED ? q : (q < 255u ? q : 255u);
 }
 
 // Correctly rounded square root and quotient WITHOUT the range handling hipcc wraps around them (LEAN instantiation).
@@ -306,7 +312,7 @@ DI uint32_t ch_pixel(uint32_t mode, const ChConst& k, float dx, float xx, float 
         const float kk = 1.0f - t;
         col = mk(1.0f * kk + 0.5f * t, 1.0f * kk + 0.7f * t, 1.0f * kk + 1.0f * t);
     }
-    return pack_rgb(ch_unorm8(col.x), ch_unorm8(col.y), ch_unorm8(col.z));  // alpha byte 0 (raytrace06.comp:66)
+    return pack_rgb(ch_unorm8<LEAN>(col.x), ch_unorm8<LEAN>(col.y), ch_unorm8<LEAN>(col.z));  // alpha byte 0 (raytrace06.comp:66)
 }
 
 constexpr uint32_t kChTileCols = 256;  // columns of a workgroup's tile: 64 lanes x 4 pixels
