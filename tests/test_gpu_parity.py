@@ -107,6 +107,13 @@ def test_ch_lean_roots_and_quotients_equal_the_full_forms_and_the_oracle(gpu_ctx
         u.viewportHeight = float(np.float32(10.0 ** rng.uniform(-3, 3)))
         u.focalLength = float(np.float32(10.0 ** rng.uniform(-3, 3)))
         ubos.append(u)
+    # ... and UBOs at the corners of the lean range, where a unit vector's component IS +-1 and a colour channel 0 or 1 to the last
+    # bit (the lean kernels' quantiser has no clamp: ch_unorm8<true>)
+    for vw, vh, f in ((2.0 ** -19, 2.0 ** 19, 2.0 ** -19), (2.0 ** 19, 2.0 ** -19, 2.0 ** -19), (2.0 ** -19, 2.0 ** -19, 2.0 ** 19),
+                      (2.0 ** 19, 2.0 ** 19, 2.0 ** 19), (1.5, 2.0 ** 19, 0.75), (2.0 ** 19, 1.0, 2.0 ** -19)):
+        u = V.ubo_from_image(97, 61)
+        u.viewportWidth, u.viewportHeight, u.focalLength = vw, vh, f
+        ubos.append(u)
     for vw, vh, f in ((1e-9, 2.0, 1.0), (2.0, 3e8, 1.0), (2.0, 1.0, 1e-12), (-2.0, 1.125, 1.0), (2.0, -1.0, 5e7)):
         u = V.ubo_from_image(96, 64)
         u.viewportWidth, u.viewportHeight, u.focalLength = vw, vh, f
