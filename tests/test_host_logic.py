@@ -72,13 +72,35 @@ def test_cluster_build_boxes_contain_their_spheres_and_the_flat_interval_contain
     if b["flat_axis"] < 3:
         fa = b["flat_axis"]
         mid, half = b["flat_interval"]
-        occupied = [k for k in range(b["n_clusters"] + b["n_super"]) if boxes[k, 3:].max() > 0]   # (padding boxes are points far away)
+        # (the CLUSTER boxes: a super-cluster's own interval is the union of its clusters' rounded outwards once more, and what the
+        # kernel tests in its place is the common interval with the super's two other axes, which contain its clusters')
+        occupied = [k for k in range(b["n_clusters"]) if boxes[k, 3:].max() > 0]   # (padding boxes are points far away)
         assert all(lo[k, fa] >= mid - half and hi[k, fa] <= mid + half for k in occupied), kind
         others = [ax for ax in range(3) if ax != fa]
         want = np.concatenate([b["boxes"][:, others], b["boxes"][:, [3 + others[0], 3 + others[1]]]], 1)
         assert np.array_equal(b["flat_boxes"], want)
         own = (hi[occupied, fa] - lo[occupied, fa]).min()
         assert 2 * half <= 1.5 * own * (1 + 1e-6)                     # never taken when a box is much narrower than the union
+
+
+@pytest.mark.parametrize("grid_half", [14, 20, 28, 36])
+def test_super_clusters_are_subtrees_of_the_build(grid_half):
+    """The eight clusters under a super-cluster's box are one subtree of the build's median splits -- the splits of a scene that
+    gets super-clusters are rounded to whole super-clusters -- so the super boxes tile the scene: on cover scenes of 785 .. 5185
+    spheres (56 .. 328 clusters, none a power of two) their footprints add up to little more than the scene's own.  (Rounded to
+    whole clusters only, a super-cluster straddled two subtrees wherever the count was not a power of two: the 3138-sphere
+    scene's footprints added up to several times the scene and a ray made 103 tests per segment instead of 59.)"""
+    sph, _ = V.make_cover_scene(1, grid_half)
+    b = V.cluster_build_host(sph)
+    assert b["n_super"] == b["n_clusters"] // 8 and b["n_super"] > 0 and b["flat_axis"] == 1
+    sup = b["boxes"][b["n_clusters"]:].astype(np.float64)
+    sup = sup[sup[:, 3:].max(axis=1) > 0]
+    footprint = (2 * sup[:, 3]) * (2 * sup[:, 5])
+    lo = (sup[:, [0, 2]] - sup[:, [3, 5]]).min(axis=0)
+    hi = (sup[:, [0, 2]] + sup[:, [3, 5]]).max(axis=0)
+    scene = (hi - lo).prod()
+    assert footprint.sum() <= 1.35 * scene, (footprint.sum(), scene)
+    assert footprint.max() <= 4.0 * scene / len(sup), (footprint.max(), scene / len(sup))
 
 
 def test_header_is_plain_c_and_links(tmp_path):

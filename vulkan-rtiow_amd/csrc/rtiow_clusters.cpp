@@ -78,6 +78,12 @@ void build_clusters(const RtSphere* sph, uint32_t n, double range_diags, Cluster
     // the median of its longest axis, the left part rounded to whole clusters, and recurse.  (Runs of a
     // Morton curve give boxes a ray meets 2.1x as often on the cover scene: tools/cull_sim.py.)
     struct Range { size_t lo, hi; };
+    constexpr size_t kSuperSpan = size_t(kSuperSize) * kClusterSize;  // spheres under one super-cluster
+    uint32_t super_from = kSuperFrom;
+    if (const char* v = std::getenv("RTIOW_DEBUG_SUPER_FROM")) super_from = static_cast<uint32_t>(std::strtoul(v, nullptr, 10));  // tuning only
+    // (the padded cluster count, as computed below)
+    const size_t clusters_to_be = ((small.size() + kClusterSize - 1u) / kClusterSize + kSuperSize - 1u) / kSuperSize * kSuperSize;
+    const bool with_supers = clusters_to_be > super_from;
     std::vector<Range> todo{{0, small.size()}};
     while (!todo.empty()) {
         const Range rg = todo.back();
@@ -102,6 +108,14 @@ void build_clusters(const RtSphere* sph, uint32_t n, double range_diags, Cluster
         });
         size_t left = (count / 2 + kClusterSize / 2) / kClusterSize * kClusterSize;
         if (left == 0) left = kClusterSize;
+        // A scene that gets super-clusters (below) splits its larger ranges at whole SUPER-clusters, so that the kSuperSize
+        // consecutive clusters under one super box are one subtree of the splits: rounded to whole clusters only, a super
+        // straddled the boundary of two subtrees wherever the cluster count was not a power of two -- two distant corners under
+        // one box -- and a 3138-sphere scene (200 clusters) made 103 tests per segment where the 4099-sphere one (256) makes 68.
+        if (with_supers && count > kSuperSpan) {
+            left = (count / 2 + kSuperSpan / 2) / kSuperSpan * kSuperSpan;
+            if (left == 0) left = kSuperSpan;
+        }
         if (left >= count) left = count - 1;
         todo.push_back({rg.lo, rg.lo + left});
         todo.push_back({rg.lo + left, rg.hi});
@@ -164,7 +178,7 @@ void build_clusters(const RtSphere* sph, uint32_t n, double range_diags, Cluster
     // the split tree), boxed by the union of their clusters' boxes.  The kernel then tests the super
     // boxes in lock-step and the cluster boxes only for the (ray, super-cluster) pairs that pass.
     out.n_super = 0;
-    if (out.n_clusters > kSuperFrom) {
+    if (out.n_clusters > super_from) {
         out.n_super = out.n_clusters / kSuperSize;
         for (uint32_t sc = 0; sc < out.n_super; ++sc) {
             double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};

@@ -69,9 +69,13 @@ struct ShadeRec {
 // the kernel, a stride of 16 slots (256 B = one LDS bank row) makes the bank of a read depend on the
 // lane only: conflict-free.
 constexpr uint32_t kClusterSize = 16, kClusterStride = 16;
-// Super-clusters (large scenes only): kSuperSize consecutive clusters under one box, from kSuperFrom
-// clusters on.
-constexpr uint32_t kSuperSize = 8, kSuperFrom = 96;  // measured: the extra stage costs about as much as 80 box tests per ray
+// Super-clusters (large scenes only): kSuperSize consecutive clusters -- one subtree of the build's splits -- under one box, from
+// more than kSuperFrom clusters on.  (Rounds 1-3: 96, "the extra stage costs about as much as 80 box tests per ray".  With the
+// splits rounded to whole super-clusters -- rtiow_clusters.cpp: before, a super box straddled two subtrees wherever the cluster
+// count was not a power of two -- and the boxes tested without their flat axis, the level pays from 40 clusters on: cover scenes of
+// 785 / 1026 spheres (56 / 64 clusters) 3.40 -> 3.05 / 3.39 -> 2.98 ms at 32 spp, 59.5 -> 30.5 / 62.9 -> 32.2 tests per segment.
+// 40 clusters are more than 624 spheres: beyond what the small-scene kernels, compiled without this level, ever hold.)
+constexpr uint32_t kSuperSize = 8, kSuperFrom = 40;
 
 struct PathArgs {
     const float4* spheres;       // n x {cx,cy,cz,radius} as uploaded (RtSphere)

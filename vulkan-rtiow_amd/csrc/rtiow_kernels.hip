@@ -1135,7 +1135,7 @@ DI void walk_clusters(const float4* slots, const uint32_t* idx_map, const PathAr
 }
 
 // SUPER: the instantiation can meet super-clusters (a.n_super != 0).  Small scenes -- those whose shading records sit
-// in LDS, at most ~580 spheres -- never have them (kSuperFrom clusters = 1536 spheres): their kernel is compiled
+// in LDS, at most ~580 spheres -- never have them (more than kSuperFrom clusters = more than 624 spheres): their kernel is compiled
 // without that level, which is a third of this function and would otherwise weigh on its register allocation.
 // FLAT: the boxes are tested without their flat axis (slab_gap_flat; `bounds` then holds one float4 per box).
 template <int R, bool SUPER, bool FLAT>
@@ -3246,6 +3246,11 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // camera paths a pass may make: one per lane, and no more than the records hold (those beyond pass_keep lie in the
     // work-list area: 42 of them, or all 64 in the two-level one)
     g.pass_min_idle = kPassMinLanes > g.pass_keep ? kPassMinLanes - g.pass_keep : 1u;
+    // (the large-scene variant, the only one that looks at it: with records of its own it still waits for 16 idle slots -- a pass
+    // of its two-level culls for a handful of rays costs more than the slots it fills; cover scenes of 1026 / 1938 / 3138 spheres
+    // 5.78 -> 5.48, 6.73 -> 6.61, 7.52 -> 7.28 ms at 64 spp, tools/keep_ab.py)
+    if (!shade_lds && g.pass_keep != 0u && g.pass_min_idle < 16u) g.pass_min_idle = 16u;
+    if (const char* v = getenv("RTIOW_DEBUG_PASS_MIN_IDLE")) g.pass_min_idle = strtoul(v, nullptr, 10);  // tuning only
     g.pass_cap = g.pass_keep + item_bytes / kPassRecBytes;
     if (g.pass_cap > 64u) g.pass_cap = 64u;
     if (accel) {
