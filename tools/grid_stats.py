@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vulkan_rtiow_amd as V
 w, h = 1200, 800
-for grid in (11, 14, 16, 20, 22, 24, 28, 30, 32, 36):
+for grid in [int(x) for x in os.environ.get("GRIDS", "11,14,16,20,22,24,28,30,32,36").split(",")]:
     sph, mat = V.make_cover_scene(1, grid)
     cam = V.make_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, w / h, 0.1, 10.0)
     with V.Context(0) as ctx:

@@ -72,10 +72,11 @@ constexpr uint32_t kClusterSize = 16, kClusterStride = 16;
 // Super-clusters (large scenes only): kSuperSize consecutive clusters -- one subtree of the build's splits -- under one box, from
 // more than kSuperFrom clusters on.  (Rounds 1-3: 96, "the extra stage costs about as much as 80 box tests per ray".  With the
 // splits rounded to whole super-clusters -- rtiow_clusters.cpp: before, a super box straddled two subtrees wherever the cluster
-// count was not a power of two -- and the boxes tested without their flat axis, the level pays from 40 clusters on: cover scenes of
-// 785 / 1026 spheres (56 / 64 clusters) 3.40 -> 3.05 / 3.39 -> 2.98 ms at 32 spp, 59.5 -> 30.5 / 62.9 -> 32.2 tests per segment.
-// 40 clusters are more than 624 spheres: beyond what the small-scene kernels, compiled without this level, ever hold.)
-constexpr uint32_t kSuperSize = 8, kSuperFrom = 40;
+// count was not a power of two -- and the boxes tested without their flat axis, the level pays as soon as the scene is beyond
+// the small-scene kernels (which are compiled without it and hold 32 clusters at most): cover scenes of 576 / 785 / 1026 spheres
+// (40 / 56 / 64 clusters) 3.04 -> 2.8 / 3.40 -> 3.05 / 3.39 -> 2.98 ms at 32 spp, 44.8 -> 27 / 59.5 -> 30.5 / 62.9 -> 32.2 tests
+// per segment.)
+constexpr uint32_t kSuperSize = 8, kSuperFrom = 32;
 
 struct PathArgs {
     const float4* spheres;       // n x {cx,cy,cz,radius} as uploaded (RtSphere)

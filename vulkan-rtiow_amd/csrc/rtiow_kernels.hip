@@ -1135,7 +1135,7 @@ DI void walk_clusters(const float4* slots, const uint32_t* idx_map, const PathAr
 }
 
 // SUPER: the instantiation can meet super-clusters (a.n_super != 0).  Small scenes -- those whose shading records sit
-// in LDS, at most ~580 spheres -- never have them (more than kSuperFrom clusters = more than 624 spheres): their kernel is compiled
+// in LDS, at most ~510 spheres -- never have them (more than kSuperFrom clusters = more than 512 small spheres): their kernel is compiled
 // without that level, which is a third of this function and would otherwise weigh on its register allocation.
 // FLAT: the boxes are tested without their flat axis (slab_gap_flat; `bounds` then holds one float4 per box).
 template <int R, bool SUPER, bool FLAT>
@@ -3199,10 +3199,11 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // and result keys).
     const size_t lds_geo = static_cast<size_t>(g.n_pad) * sizeof(float4) +
                            (accel ? static_cast<size_t>(g.n_pad) * 4u + static_cast<size_t>(a.n_clusters + a.n_super) * box_bytes : 0u);
-    const bool shade_lds = lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 28u * 1024u &&
+    // (a scene with super-clusters -- more than kSuperFrom clusters, i.e. more than 512 small spheres: 30 KB at least -- is never a
+    // small one: the small-scene kernels are compiled without that level)
+    const bool shade_lds = a.n_super == 0u && lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 28u * 1024u &&
                            !getenv("RTIOW_DEBUG_NO_SHADE_LDS");  // (tuning only)
     const size_t lds_scene = lds_geo + (shade_lds ? static_cast<size_t>(a.n) * sizeof(ShadeRec) : 0u);
-    if (shade_lds && a.n_super != 0u) return hipErrorInvalidValue;  // (cannot happen: see trace_clustered's SUPER)
     // the clustered kernels' primary pass keeps up to pass_keep camera paths per wave in LDS records of their own; a
     // large scene with no room for them (C5: one 768-thread group beside 92 KB of list) does without -- its passes then
     // make no more paths than there are idle slots, and the records sit in the two-level work-list area alone
