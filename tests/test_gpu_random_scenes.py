@@ -153,6 +153,45 @@ def test_rays_from_outside_the_box_range(gpu_ctx, oracle, n):
         assert int((got != want).any(axis=2).sum()) == 0 and st.segments == segs
 
 
+@pytest.mark.parametrize("n", [700, 2500])
+def test_many_samples_per_pixel_on_a_large_scene(gpu_ctx, oracle, n):
+    """Many samples per pixel on a scene of the large-scene kernels (super-clusters from 40 clusters on: both sizes have them):
+    every primary pass of a wave hands out one pixel, pass after pass.  Whole frame against the oracle and against the flat
+    list, as one dispatch and as tiles."""
+    rng = np.random.default_rng(900 + n)
+    sph = np.zeros(n + 1, V.SPHERE_DTYPE)
+    mat = np.zeros(n + 1, V.MATERIAL_DTYPE)
+    side = int(np.ceil(np.sqrt(n)))
+    ij = rng.permutation(side * side)[:n]
+    sph["cx"][1:] = (ij % side) - side / 2 + rng.uniform(0.1, 0.7, n)
+    sph["cz"][1:] = (ij // side) - side / 2 + rng.uniform(0.1, 0.7, n)
+    sph["cy"][1:] = 0.2
+    sph["radius"][1:] = 0.2
+    kinds = rng.choice([0, 1, 2], n, p=[0.7, 0.2, 0.1])
+    mat["kind"][1:] = kinds
+    mat["albedo"][1:] = rng.uniform(0.2, 0.9, (n, 3))
+    mat["fuzz"][1:] = np.where(kinds == 1, rng.uniform(0, 0.4, n), 0)
+    mat["ior"][1:] = np.where(kinds == 2, 1.5, 0)
+    sph[0] = (0.0, -1000.0, 0.0, 1000.0)
+    mat[0] = (0, (0.5, 0.5, 0.5), 0.0, 0.0, (0, 0))
+    w, h = 24, 10
+    cam = V.make_camera((9, 2.5, 4), (0, 0, 0), (0, 1, 0), 25.0, w / h, 0.15, 9.0)
+    base = dict(spp=400, max_depth=8, seed=11)
+    want, segs = oracle.render(sph, mat, cam, V.make_params(w, h, **base))
+    gpu_ctx.set_scene(sph, mat)
+    flat = gpu_ctx.render(cam, V.make_params(w, h, kernel=V.KERNEL_PERSISTENT, **base))
+    assert np.array_equal(flat, want) and gpu_ctx.stats().segments == segs
+    for kernel in (V.KERNEL_CLUSTERED, V.KERNEL_CLUSTERED_PASS):
+        got = gpu_ctx.render(cam, V.make_params(w, h, kernel=kernel, **base))
+        assert gpu_ctx.last_kernel() == V.KERNEL_CLUSTERED
+        st = gpu_ctx.stats()
+        assert np.array_equal(got, want) and st.segments == segs
+        tiles = [gpu_ctx.render(cam, V.make_params(w, h, kernel=kernel, row_block=2, tile_rank=r, tile_count=2, **base)) for r in range(2)]
+        rows = [np.array([y for y in range(h) if (y // 2) % 2 == r]) for r in range(2)]
+        for r in range(2):
+            assert np.array_equal(tiles[r], want[rows[r]])
+
+
 @pytest.mark.parametrize("case", range(14))
 def test_primary_pass_extreme_cameras(gpu_ctx, oracle, case):
     """The cone cull of the primary pass (RtParams.kernel 4 forces it at these sample counts) at the edges of its
