@@ -1161,6 +1161,11 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
         az[r] = -p.o.z * iz[r];
         const float qx = p.o.x - a.ccenter[0], qy = p.o.y - a.ccenter[1], qz = p.o.z - a.ccenter[2];
         outside[r] = !(fma_(qz, qz, fma_(qy, qy, qx * qx)) <= a.crmax2);
+        if constexpr (SUPER && !FLAT) {
+            // (large scenes, see the FLAT case below: a ray outside the boxes' range gets the reciprocal direction every box lets
+            // through -- 0 * box + 0 -- so that the expansion stage can fetch these six numbers instead of the ray)
+            if (outside[r]) ix[r] = iy[r] = iz[r] = ax[r] = ay[r] = az[r] = 0.0f;
+        }
         if (FLAT) {  // (ix, iz, ax, az become the two box axes; iy, ay the ray's interval in the common slab)
             const FlatRay f = flat_ray(a, ix[r], iy[r], iz[r], ax[r], ay[r], az[r]);
             ix[r] = f.ia;
@@ -1438,31 +1443,28 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
                         DBG_ADD(dbg_cands, __builtin_popcount(hit8));
                     }
                 }
-                float ox = 0.0f, oy = 0.0f, oz = 0.0f, dx = 0.0f, dy = 0.0f, dz = 0.0f;
-                if constexpr (!FLAT) fetch_item_ray(sl, item, ox, oy, oz, dx, dy, dz);
-                if (!FLAT && valid) {
-                    const float jx = slab_rcp(dx), jy = slab_rcp(dy), jz = slab_rcp(dz);
-                    const float bx = -ox * jx, by = -oy * jy, bz = -oz * jz;
-                    const float qx = ox - a.ccenter[0], qy = oy - a.ccenter[1], qz = oz - a.ccenter[2];
-                    const bool out = !(fma_(qz, qz, fma_(qy, qy, qx * qx)) <= a.crmax2);
-                    const uint32_t first = (s0 + (item >> 7)) * kSuperSize;
-                    [[maybe_unused]] FlatRay f{};
-                    if (FLAT) f = flat_ray(a, jx, jy, jz, bx, by, bz);
+                if constexpr (!FLAT) {  // the same with whole boxes: reciprocal direction and -o/d of the item's ray from its owner
+                    const int src = static_cast<int>(item & 63u);
+                    const bool second = R > 1 && (item & 64u) != 0u;
+                    float fr[6];
+                    const float* own[6] = {ix, iy, iz, ax, ay, az};
 #pragma unroll
-                    for (uint32_t j = 0; j < kSuperSize; ++j) {
-                        const uint32_t k = (j + lane) & (kSuperSize - 1u);  // lane-rotated: spreads the LDS banks
-                        bool reach;
-                        if (FLAT) {
-                            reach = !__builtin_signbit(slab_gap_flat(bounds[first + k], f.ia, f.ib, f.oa, f.ob, f.tn_f, f.tf_f));
-                        } else {
-                            const float4 mid = bounds[2u * (first + k)], half = bounds[2u * (first + k) + 1u];
-                            reach = !__builtin_signbit(slab_gap(mid, half, jx, jy, jz, bx, by, bz));
-                        }
-                        hit8 |= (reach ? 1u : 0u) << k;
+                    for (int v = 0; v < 6; ++v) {
+                        const float v0 = __shfl(own[v][0], src), v1 = __shfl(own[v][R - 1], src);
+                        fr[v] = second ? v1 : v0;
                     }
-                    if (out) hit8 = (1u << kSuperSize) - 1u;
-                    n_tests += kSuperSize;
-                    DBG_ADD(dbg_cands, __builtin_popcount(hit8));
+                    if (valid) {
+                        const uint32_t first = (s0 + (item >> 7)) * kSuperSize;
+#pragma unroll
+                        for (uint32_t j = 0; j < kSuperSize; ++j) {
+                            const uint32_t k = (j + lane) & (kSuperSize - 1u);  // lane-rotated: spreads the LDS banks
+                            const float4 mid = bounds[2u * (first + k)], half = bounds[2u * (first + k) + 1u];
+                            const bool reach = !__builtin_signbit(slab_gap(mid, half, fr[0], fr[1], fr[2], fr[3], fr[4], fr[5]));
+                            hit8 |= (reach ? 1u : 0u) << k;
+                        }
+                        n_tests += kSuperSize;
+                        DBG_ADD(dbg_cands, __builtin_popcount(hit8));
+                    }
                 }
                 const uint32_t cnt = static_cast<uint32_t>(__builtin_popcount(hit8));
                 const uint32_t incl2 = wave_inclusive_sum(cnt);
