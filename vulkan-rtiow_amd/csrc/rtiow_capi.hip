@@ -161,6 +161,8 @@ static int upload_clusters(RtContext* ctx, double range_diags) {
     for (int k = 0; k < 3; ++k) ctx->cluster_center[k] = cs.center[k];
     ctx->cluster_diag = cs.diag;
     ctx->cluster_rmax2 = cs.rmax2;
+    ctx->cluster_far_k = cs.far_k;
+    ctx->cluster_far_c = cs.far_c;
     ctx->cluster_range = range_diags < 2.0 ? 2.0 : range_diags;
     return RT_OK;
 }
@@ -311,6 +313,8 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         a.flat_half = ctx->flat_half;
         for (int k = 0; k < 3; ++k) a.ccenter[k] = ctx->cluster_center[k];
         a.crmax2 = ctx->cluster_rmax2;
+        a.cfar_k = ctx->cluster_far_k;
+        a.cfar_c = ctx->cluster_far_c;
         a.n = ctx->n_spheres;
         a.cam = *cam;
         a.width = W;
@@ -374,6 +378,8 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
                 a.flat_half = ctx->flat_half;
                 for (int k = 0; k < 3; ++k) a.ccenter[k] = ctx->cluster_center[k];
                 a.crmax2 = ctx->cluster_rmax2;
+                a.cfar_k = ctx->cluster_far_k;
+                a.cfar_c = ctx->cluster_far_c;
             }
         }
         // cost-ordered dequeue (persistent kernels): this frame is dealt in the order the last frame of the

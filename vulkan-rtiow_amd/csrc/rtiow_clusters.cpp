@@ -73,6 +73,13 @@ void build_clusters(const RtSphere* sph, uint32_t n, double range_diags, Cluster
     const double oc_max = rmax * 1.05 + 0.5 * diag;  // rmax + diag/2, and the rounding of the kernel's own range check
     const double r2_margin = 48.0 * kEps * oc_max * oc_max;
     const double plane_margin = 64.0 * kEps * (cmax + rmax + diag) + 1e-30;
+    // Rays that start farther out, q from the centre: the same two margins with q for rmax are sqrt(r^2 + 48 eps (1.05 q + diag/2)^2)
+    // - r <= sqrt(48 eps) (1.05 q + diag/2) for the sphere and 64 eps (cmax + q + diag) for the planes, whatever the radius: a box
+    // with every half extent enlarged by far_k q + far_c contains what such a ray's exact test can accept.  Linear in q, so the
+    // kernel works it out per ray (trace_clustered, the expansion stage of the two-level trace: a ground plane that reaches the
+    // horizon starts a few rays in a thousand out there, and each of them used to take EVERY cluster of a large scene).
+    out.far_k = round_up((1.05 * std::sqrt(48.0 * kEps) + 64.0 * kEps) * 1.001);
+    out.far_c = round_up((0.5 * diag * std::sqrt(48.0 * kEps) + 64.0 * kEps * (cmax + diag) + 1e-30) * 1.001);
 
     // Order the small spheres so that every run of kClusterSize is a compact group: split the set at
     // the median of its longest axis, the left part rounded to whole clusters, and recurse.  (Runs of a

@@ -39,7 +39,7 @@ struct RtContext {
     uint32_t flat_axis = 3;       // (rtiow_clusters.cpp: the axis all cluster boxes share an interval along; 3: none)
     float flat_mid = 0, flat_half = 0;
     float cluster_center[3] = {0, 0, 0};
-    float cluster_diag = 0, cluster_rmax2 = 0;
+    float cluster_diag = 0, cluster_rmax2 = 0, cluster_far_k = 0, cluster_far_c = 0;
     uint32_t last_kernel = 0;     // variant the last PATH render launched
     std::vector<RtSphere> host_spheres;  // kept to re-box the clusters for a camera farther out
     double cluster_range = 0;     // range_diags the current boxes were built for

@@ -97,6 +97,7 @@ struct PathArgs {
     uint32_t n_cslots;           // n_large_slots + n_clusters * kClusterStride
     float ccenter[3];            // boxes are valid for ray origins with |o - ccenter|^2 <= crmax2
     float crmax2;
+    float cfar_k, cfar_c;        // ... and, every half extent enlarged by cfar_k |o - ccenter| + cfar_c, for any origin (far_box_margin)
     RtCamera cam;
     uint32_t width, height;      // full image
     uint32_t spp, max_depth, seed, quantiser;
@@ -146,6 +147,7 @@ struct ClusterScene {  // host-side result of build_clusters
     float diag = 0;               // their extent
     float rmax2 = 0;              // (range_diags diag)^2: ray origins farther from the centre are outside
                                   // the rounding margin the boxes were inflated for
+    float far_k = 0, far_c = 0;   // a ray that starts q from the centre may use the boxes enlarged by far_k q + far_c
 };
 // range_diags: ray origins up to this many scene diagonals from the scene's centre use the boxes (>= 2)
 void build_clusters(const RtSphere* spheres, uint32_t n, double range_diags, ClusterScene& out);

@@ -1036,7 +1036,7 @@ HDI float slab_gap_flat(const float4& box, float ia, float ib, float oa, float o
 struct FlatRay {
     float ia, ib, oa, ob, tn_f, tf_f;
 };
-DI FlatRay flat_ray(const PathArgs& a, float ix, float iy, float iz, float ax, float ay, float az) {
+DI FlatRay flat_ray(const PathArgs& a, float ix, float iy, float iz, float ax, float ay, float az, float extra = 0.0f) {
     const uint32_t fa = a.flat_axis;  // (wave-uniform)
     const float i_f = fa == 0u ? ix : (fa == 1u ? iy : iz), o_f = fa == 0u ? ax : (fa == 1u ? ay : az);
     FlatRay f;
@@ -1045,9 +1045,17 @@ DI FlatRay flat_ray(const PathArgs& a, float ix, float iy, float iz, float ax, f
     f.ib = fa == 2u ? iy : iz;
     f.ob = fa == 2u ? ay : az;
     const float tc = fma_(a.flat_mid, i_f, o_f), jf = __builtin_fabsf(i_f);
-    f.tn_f = __builtin_fmaxf(fma_(-a.flat_half, jf, tc), 0.0f);
-    f.tf_f = fma_(a.flat_half, jf, tc);
+    const float fh = a.flat_half + extra;  // (extra: far_box_margin, for a ray that starts outside the boxes' range)
+    f.tn_f = __builtin_fmaxf(fma_(-fh, jf, tc), 0.0f);
+    f.tf_f = fma_(fh, jf, tc);
     return f;
+}
+
+// What to add to every half extent of a box (and of the common interval of a flat scene) for a ray that starts at `o`, anywhere:
+// rtiow_clusters.cpp, far_k / far_c (the root is v_sqrt_f32's, 1 ulp: the factors carry 0.1 % of slack).
+DI float far_box_margin(const PathArgs& a, float ox, float oy, float oz) {
+    const float qx = ox - a.ccenter[0], qy = oy - a.ccenter[1], qz = oz - a.ccenter[2];
+    return fma_(a.cfar_k, __builtin_amdgcn_sqrtf(fma_(qz, qz, fma_(qy, qy, qx * qx))), a.cfar_c);
 }
 
 // Box number i of the clustered list (clusters first, then super-clusters) as centre + half extent.  !FLAT: as stored.
@@ -1148,6 +1156,7 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
     unsigned long long key[R];
     float ix[R], iy[R], iz[R], ax[R], ay[R], az[R];
     bool outside[R];  // ray origin beyond the range the boxes were inflated for: take every cluster
+    [[maybe_unused]] float far_add[R];  // (SUPER) ... of the top level, and the cluster boxes enlarged by this much (0: within the range)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         key[r] = ~0ull;
@@ -1161,28 +1170,21 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
         az[r] = -p.o.z * iz[r];
         const float qx = p.o.x - a.ccenter[0], qy = p.o.y - a.ccenter[1], qz = p.o.z - a.ccenter[2];
         outside[r] = !(fma_(qz, qz, fma_(qy, qy, qx * qx)) <= a.crmax2);
-        if constexpr (SUPER && !FLAT) {
-            // (large scenes, see the FLAT case below: a ray outside the boxes' range gets the reciprocal direction every box lets
-            // through -- 0 * box + 0 -- so that the expansion stage can fetch these six numbers instead of the ray)
-            if (outside[r]) ix[r] = iy[r] = iz[r] = ax[r] = ay[r] = az[r] = 0.0f;
+        if constexpr (SUPER) {
+            // Large scenes: a ray that starts outside the range takes every SUPER-cluster (their lock-step test says nothing about
+            // it), but in the expansion stage below -- one lane per (ray, super-cluster) pair anyway -- its cluster boxes are tested
+            // enlarged by what a ray from that far needs (far_box_margin): C5's horizon starts a few rays in a thousand out there,
+            // and each of them used to take all 256 clusters, 4096 member tests.
+            far_add[r] = outside[r] ? far_box_margin(a, p.o.x, p.o.y, p.o.z) : 0.0f;
         }
         if (FLAT) {  // (ix, iz, ax, az become the two box axes; iy, ay the ray's interval in the common slab)
-            const FlatRay f = flat_ray(a, ix[r], iy[r], iz[r], ax[r], ay[r], az[r]);
+            const FlatRay f = flat_ray(a, ix[r], iy[r], iz[r], ax[r], ay[r], az[r], SUPER ? far_add[r] : 0.0f);
             ix[r] = f.ia;
             iz[r] = f.ib;
             ax[r] = f.oa;
             az[r] = f.ob;
             iy[r] = f.tn_f;
             ay[r] = f.tf_f;
-            if constexpr (SUPER) {
-                // (large scenes: a ray that starts outside the boxes' range takes every box -- its own values are never looked at
-                // in the lock-step stages -- and is given the flat ray every box lets through, so that the expansion stage below
-                // can fetch these six numbers instead of the ray and needs no flag: 0 * box + 0 within [0, inf))
-                if (outside[r]) {
-                    ix[r] = iz[r] = ax[r] = az[r] = iy[r] = 0.0f;
-                    ay[r] = __builtin_inff();
-                }
-            }
         }
     }
     // one box against the ray of slot r: sign bit set = not reached
@@ -1424,10 +1426,10 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
                     // cover scenes of 785 / 2304 / 4099 spheres -2.9 / -2.0 / -1.8 %)
                     const int src = static_cast<int>(item & 63u);
                     const bool second = R > 1 && (item & 64u) != 0u;
-                    float fr[6];
-                    const float* own[6] = {ix, iz, ax, az, iy, ay};
+                    float fr[7];
+                    const float* own[7] = {ix, iz, ax, az, iy, ay, far_add};
 #pragma unroll
-                    for (int v = 0; v < 6; ++v) {
+                    for (int v = 0; v < 7; ++v) {
                         const float v0 = __shfl(own[v][0], src), v1 = __shfl(own[v][R - 1], src);
                         fr[v] = second ? v1 : v0;
                     }
@@ -1436,7 +1438,10 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
 #pragma unroll
                         for (uint32_t j = 0; j < kSuperSize; ++j) {
                             const uint32_t k = (j + lane) & (kSuperSize - 1u);  // lane-rotated: spreads the LDS banks
-                            const bool reach = !__builtin_signbit(slab_gap_flat(bounds[first + k], fr[0], fr[1], fr[2], fr[3], fr[4], fr[5]));
+                            float4 b = bounds[first + k];
+                            b.z += fr[6];  // (0 for a ray within the range: the box as stored)
+                            b.w += fr[6];
+                            const bool reach = !__builtin_signbit(slab_gap_flat(b, fr[0], fr[1], fr[2], fr[3], fr[4], fr[5]));
                             hit8 |= (reach ? 1u : 0u) << k;
                         }
                         n_tests += kSuperSize;
@@ -1446,10 +1451,10 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
                 if constexpr (!FLAT) {  // the same with whole boxes: reciprocal direction and -o/d of the item's ray from its owner
                     const int src = static_cast<int>(item & 63u);
                     const bool second = R > 1 && (item & 64u) != 0u;
-                    float fr[6];
-                    const float* own[6] = {ix, iy, iz, ax, ay, az};
+                    float fr[7];
+                    const float* own[7] = {ix, iy, iz, ax, ay, az, far_add};
 #pragma unroll
-                    for (int v = 0; v < 6; ++v) {
+                    for (int v = 0; v < 7; ++v) {
                         const float v0 = __shfl(own[v][0], src), v1 = __shfl(own[v][R - 1], src);
                         fr[v] = second ? v1 : v0;
                     }
@@ -1458,7 +1463,11 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
 #pragma unroll
                         for (uint32_t j = 0; j < kSuperSize; ++j) {
                             const uint32_t k = (j + lane) & (kSuperSize - 1u);  // lane-rotated: spreads the LDS banks
-                            const float4 mid = bounds[2u * (first + k)], half = bounds[2u * (first + k) + 1u];
+                            const float4 mid = bounds[2u * (first + k)];
+                            float4 half = bounds[2u * (first + k) + 1u];
+                            half.x += fr[6];  // (0 for a ray within the range: the box as stored)
+                            half.y += fr[6];
+                            half.z += fr[6];
                             const bool reach = !__builtin_signbit(slab_gap(mid, half, fr[0], fr[1], fr[2], fr[3], fr[4], fr[5]));
                             hit8 |= (reach ? 1u : 0u) << k;
                         }
