@@ -1387,27 +1387,30 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
                 if (sl[r].active) n_tests += jn;
                 packed += static_cast<uint32_t>(__builtin_popcount(sm[r]));
             }
-            const uint32_t incl = wave_inclusive_sum(packed);
+            const uint32_t incl_all = wave_inclusive_sum(packed);
+            const uint32_t total_all = __builtin_amdgcn_readlane(incl_all, 63);
+            if (total_all == 0u) continue;
+            // A list that would overflow -- many rays that start outside the boxes' range: 32 items each -- is worked off sixteen
+            // lanes of one slot at a time (16 x 32 items fit): every ray still goes through the expansion stage, where a far ray's
+            // boxes are tested enlarged.  (Rounds 1-3 walked every cluster of every candidate here, lane by lane.)
+            const uint32_t n_batches = total_all > kItemCap ? 4u * static_cast<uint32_t>(R) : 1u;
+            static_assert(16u * 32u <= kItemCap, "sixteen lanes' super-cluster items fit the list");
+            for (uint32_t bt = 0; bt < n_batches; ++bt) {
+            uint32_t part[R];
+            uint32_t packed_b = 0u;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                part[r] = n_batches == 1u || (static_cast<uint32_t>(r) == (bt >> 2) && (lane >> 4) == (bt & 3u)) ? sm[r] : 0u;
+                packed_b += static_cast<uint32_t>(__builtin_popcount(part[r]));
+            }
+            const uint32_t incl = n_batches == 1u ? incl_all : wave_inclusive_sum(packed_b);
             const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
             if (total == 0u) continue;
-            if (total > kItemCap) {  // (many rays outside the boxes' range) every cluster of every candidate, lane by lane
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    uint32_t m = sm[r];
-                    while (m) {
-                        const uint32_t bit = static_cast<uint32_t>(__builtin_clz(m));
-                        m &= ~(0x80000000u >> bit);
-                        walk_clusters(slots, idx_map, a, 0xFFFFFFFFu << (32u - kSuperSize), (s0 + bit) * kSuperSize, sl[r].p, key[r],
-                                      n_tests);
-                    }
-                }
-                continue;
-            }
             {
-                uint32_t pos = incl - packed;
+                uint32_t pos = incl - packed_b;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    uint32_t m = sm[r];
+                    uint32_t m = part[r];
                     while (m) {
                         const uint32_t bit = static_cast<uint32_t>(__builtin_clz(m));
                         m &= ~(0x80000000u >> bit);
@@ -1491,6 +1494,7 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
                 pending += tot2;
             }
             consume_items(slots, idx_map, a, items, pending, s0 * kSuperSize, sl, results, n_tests, dbg_slow_trips);
+            }  // (batches)
             DBG_ADD(dbg_t_slow, DBG_STAMP() - ts0);
         }
     }
