@@ -325,7 +325,10 @@ def test_clustered_kernels_keep_their_waves_per_simd():
     assert sorted(kinds.values()) == [(0, 0, 0), (0, 1, 0), (0, 1, 1), (1, 0, 0), (1, 1, 0), (1, 1, 1)], kinds
     for k, (small, clustered, flat) in kinds.items():
         if small and clustered:
-            assert vgpr[k] <= 128 and scratch[k] <= (48 if flat else 96), (k, vgpr[k], scratch[k])
+            # (at 128 registers the flat variant spills 60 bytes per lane since the wave-wide test of far rays joined the lock-step
+            # trace -- 32 before: the test is worth 2.6 % of the cover frame all the same; a jump beyond these bounds would say the
+            # allocation has tipped over, as it did at 84 spilled registers in round 2)
+            assert vgpr[k] <= 128 and scratch[k] <= (72 if flat else 96), (k, vgpr[k], scratch[k])
         elif clustered:
             assert vgpr[k] <= 168 and scratch[k] == 0, (k, vgpr[k], scratch[k])
         else:

@@ -679,6 +679,9 @@ constexpr uint32_t kPoolWork = RTIOW_POOL_WORK;
 #define RTIOW_LONG_WEIGHT 128
 #endif
 constexpr uint32_t kLongFrom = RTIOW_LONG_FROM, kLongWeight = RTIOW_LONG_WEIGHT;  // cost of a path of more segments than kLongFrom, for the chunk order
+#ifndef RTIOW_FAR_LOCKSTEP
+#define RTIOW_FAR_LOCKSTEP 1  // (-DRTIOW_FAR_LOCKSTEP=0: A/B only -- a ray from outside the boxes' range takes every cluster of a one-level scene)
+#endif
 #ifndef RTIOW_SLOTS
 #define RTIOW_SLOTS 2  // (-DRTIOW_SLOTS=1: ablation only -- half the paths in flight)
 #endif
@@ -1058,6 +1061,27 @@ DI float far_box_margin(const PathArgs& a, float ox, float oy, float oz) {
     return fma_(a.cfar_k, __builtin_amdgcn_sqrtf(fma_(qz, qz, fma_(qy, qy, qx * qx))), a.cfar_c);
 }
 
+// does the ray reach box c (of `bounds`) enlarged by `extra`?  (the slab test of the lock-step stages, for one box)
+template <bool FLAT>
+DI bool reaches_enlarged(const float4* bounds, const PathArgs& a, uint32_t c, float ox, float oy, float oz, float dx, float dy, float dz,
+                         float extra) {
+    const float ix = slab_rcp(dx), iy = slab_rcp(dy), iz = slab_rcp(dz);
+    const float ax = -ox * ix, ay = -oy * iy, az = -oz * iz;
+    if (FLAT) {
+        const FlatRay f = flat_ray(a, ix, iy, iz, ax, ay, az, extra);
+        float4 b = bounds[c];
+        b.z += extra;
+        b.w += extra;
+        return !__builtin_signbit(slab_gap_flat(b, f.ia, f.ib, f.oa, f.ob, f.tn_f, f.tf_f));
+    }
+    const float4 mid = bounds[2u * c];
+    float4 half = bounds[2u * c + 1u];
+    half.x += extra;
+    half.y += extra;
+    half.z += extra;
+    return !__builtin_signbit(slab_gap(mid, half, ix, iy, iz, ax, ay, az));
+}
+
 // Box number i of the clustered list (clusters first, then super-clusters) as centre + half extent.  !FLAT: as stored.
 // FLAT: the list holds the boxes without their flat axis only -- 16 bytes a box instead of 32 -- and the whole box is
 // made up with the common interval, i.e. a box that CONTAINS the real one: fine for every test that only culls (the
@@ -1309,7 +1333,31 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
             uint32_t packed = 0u;  // candidate clusters of the lane, both slots
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                cm[r] = sl[r].active ? (outside[r] ? ~0u : ~miss[r]) << (32u - jn) : 0u;  // first cluster at bit 31
+                uint32_t far_cm = ~0u;  // the clusters a ray from outside the boxes' range takes
+#if RTIOW_FAR_LOCKSTEP
+                // One wave-wide test per far ray instead of "every cluster": the ray goes to scalars (v_readlane), lane b tests box
+                // g0 + b enlarged by the ray's margin (far_box_margin), one ballot is the ray's candidate mask.  On the cover frame one
+                // scattered ray in a hundred starts out there -- the ground toward the horizon -- and its 32 items were a seventh of
+                // all the work of the member stage.
+                unsigned long long fm = __ballot(sl[r].active && outside[r]);
+                while (fm != 0ull) {
+                    const int l = __builtin_ctzll(fm);
+                    fm &= fm - 1ull;
+                    const Path& p = sl[r].p;
+                    auto of_lane = [&](float v) {
+                        return __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(__float_as_uint(v)), l)));
+                    };
+                    const float ox = of_lane(p.o.x), oy = of_lane(p.o.y), oz = of_lane(p.o.z);
+                    const float dx = of_lane(p.du.x), dy = of_lane(p.du.y), dz = of_lane(p.du.z);
+                    const uint32_t b = lane & 31u;
+                    const bool reach = b < jn && reaches_enlarged<FLAT>(bounds, a, g0 + b, ox, oy, oz, dx, dy, dz, far_box_margin(a, ox, oy, oz));
+                    const uint32_t m32 = static_cast<uint32_t>(__ballot(reach));  // bit b: cluster g0 + b (lanes 32-63 repeat 0-31)
+                    if (lane == static_cast<uint32_t>(l)) far_cm = __builtin_bitreverse32(m32);  // first cluster at bit 31, as below
+                }
+                cm[r] = sl[r].active ? (outside[r] ? far_cm : (~miss[r] << (32u - jn))) : 0u;
+#else
+                cm[r] = sl[r].active ? (outside[r] ? far_cm : ~miss[r]) << (32u - jn) : 0u;  // first cluster at bit 31
+#endif
                 if (sl[r].active) n_tests += jn;
                 packed += static_cast<uint32_t>(__builtin_popcount(cm[r]));
                 DBG_ADD(dbg_cands, __builtin_popcount(cm[r]));
