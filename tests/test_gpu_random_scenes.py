@@ -151,6 +151,9 @@ def test_rays_from_outside_the_box_range(gpu_ctx, oracle, n):
         assert gpu_ctx.last_kernel() == V.KERNEL_CLUSTERED
         st = gpu_ctx.stats()
         assert int((got != want).any(axis=2).sum()) == 0 and st.segments == segs
+        # ... and such a ray no longer takes every cluster: it tests the boxes enlarged by the margin a ray from that far needs
+        # (11 / 31 / 41 / 43 tests per segment; every cluster of every far ray was n / 2 and more)
+        assert st.sphere_tests < st.segments * max(16, n // 6), (n, st.sphere_tests / st.segments)
 
 
 @pytest.mark.parametrize("n", [700, 2500])
