@@ -124,6 +124,16 @@ int rtDestroy(RtContext* ctx) {
     return RT_OK;
 }
 
+// The range the boxes are built for when the camera (with its lens) is `need` scene diagonals from the scene's centre: the
+// scene's own (kRangeOneLevel / kRangeTwoLevel), else the first of 1 and 2 diagonals that holds the camera with a tenth to spare,
+// else twice its distance.
+static double range_for_camera(double need, bool two_level) {
+    const double base = two_level ? rtiow::kRangeTwoLevel : rtiow::kRangeOneLevel;
+    for (double r : {base, 1.0, 2.0})
+        if (r >= base && need <= 0.9 * r) return r;
+    return 2.0 * need;
+}
+
 // Builds the two-level list of the clustered kernel for ray origins up to range_diags scene diagonals
 // from the scene's centre and uploads it (the context's stream must be idle).
 static int upload_clusters(RtContext* ctx, double range_diags) {
@@ -163,7 +173,7 @@ static int upload_clusters(RtContext* ctx, double range_diags) {
     ctx->cluster_rmax2 = cs.rmax2;
     ctx->cluster_far_k = cs.far_k;
     ctx->cluster_far_c = cs.far_c;
-    ctx->cluster_range = range_diags < 2.0 ? 2.0 : range_diags;
+    ctx->cluster_range = range_diags < rtiow::kRangeFloor ? rtiow::kRangeFloor : range_diags;
     return RT_OK;
 }
 
@@ -217,7 +227,8 @@ int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materi
     if (e != hipSuccess) return fail_hip(ctx, e, "hipMemcpy(shading records)");
     RT_HIP(ctx, hipMemcpy(ctx->d_spheres, spheres, sizeof(float4) * n_spheres, hipMemcpyHostToDevice));
     ctx->host_spheres.assign(spheres, spheres + n_spheres);
-    int rc = upload_clusters(ctx, 2.0);
+    int rc = upload_clusters(ctx, rtiow::kRangeOneLevel);
+    if (rc == RT_OK && ctx->n_super != 0u) rc = upload_clusters(ctx, rtiow::kRangeTwoLevel);  // (see kRangeTwoLevel)
     if (rc != RT_OK) return rc;
     ctx->n_spheres = n_spheres;
     return RT_OK;
@@ -343,9 +354,9 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         a.next_counters = ctx->d_counters + (ctx->counter_index ^ 1u);
         // The cluster boxes are inflated for ray origins within cluster_range scene diagonals of the
         // scene's centre (rtiow_clusters.cpp); the kernel sends any ray that starts farther out through
-        // every cluster.  A camera out there would do that for all its primary rays: the boxes are rebuilt
-        // for twice its distance (wider margins; rare, so the streams are simply drained first), and again
-        // once the camera has come back to an eighth of that range.  Beyond 64
+        // every cluster (enlarged by its own margin where that is cheap).  A camera out there would lose the culls of its
+        // primary rays: the boxes are rebuilt for the next rung that holds it (range_for_camera: wider margins; rare, so the
+        // streams are simply drained first), and again once the camera is back well inside a lower rung.  Beyond 64
         // diagonals the margins swallow the boxes: flat list.
         uint32_t kernel = prm->kernel;
         if (kernel == rtiow::KERNEL_CLUSTERED || kernel == rtiow::KERNEL_CLUSTERED_PASS || kernel == rtiow::KERNEL_DEFAULT) {
@@ -357,12 +368,13 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
             const double need = (std::sqrt(d2) + double(cam->lens_radius)) / std::max(1e-30, double(ctx->cluster_diag));
             if (!(need <= 64.0)) {
                 kernel = rtiow::KERNEL_PERSISTENT;
-            } else if (need > 0.95 * ctx->cluster_range || (ctx->cluster_range > 2.0 && need < ctx->cluster_range / 8.0)) {
+            } else if (need > 0.95 * ctx->cluster_range || range_for_camera(2.0 * need, ctx->n_super != 0u) < ctx->cluster_range) {
+                // (out of the range, or so far inside that a camera twice as far out would still fit the rung below)
                 // (the old lists are read by this context's frames only: wait for the last of them -- ev_done marks the end
                 // of everything the previous render enqueued -- not for the device, where other contexts' frames are in flight)
                 if (ctx->have_done) RT_HIP(ctx, hipEventSynchronize(ctx->ev_done));
                 RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                int rc = upload_clusters(ctx, 2.0 * need);
+                int rc = upload_clusters(ctx, range_for_camera(need, ctx->n_super != 0u));
                 if (rc != RT_OK) return rc;
                 a.cslots = ctx->d_cslots;
                 a.cidx = ctx->d_cidx;

@@ -67,7 +67,8 @@ void build_clusters(const RtSphere* sph, uint32_t n, double range_diags, Cluster
     const double diag = std::sqrt(diag2);
     out.diag = static_cast<float>(diag);
     // rays that start within rmax of the centre use the boxes; |oc| <= rmax + diag/2 for them
-    const double rmax = std::max(2.0, range_diags) * diag;
+    double rmax = std::max(kRangeFloor, range_diags) * diag;
+    if (const char* v = std::getenv("RTIOW_DEBUG_RANGE")) rmax = std::atof(v) * diag;  // tuning only (tools/range_ab.py)
     out.rmax2 = static_cast<float>(rmax * rmax);
     constexpr double kEps = 5.9604644775390625e-8;  // 2^-24
     const double oc_max = rmax * 1.05 + 0.5 * diag;  // rmax + diag/2, and the rounding of the kernel's own range check

@@ -149,7 +149,14 @@ struct ClusterScene {  // host-side result of build_clusters
                                   // the rounding margin the boxes were inflated for
     float far_k = 0, far_c = 0;   // a ray that starts q from the centre may use the boxes enlarged by far_k q + far_c
 };
-// range_diags: ray origins up to this many scene diagonals from the scene's centre use the boxes (>= 2)
+// The range the boxes of a scene are inflated for, in scene diagonals from its centre, while the camera is within it (rtRender moves
+// up a rung when it is not: range_for_camera): 2 for a scene with one level of boxes -- a ray from beyond costs its wave-wide test
+// (65 instructions: cover frame 6.93 / 6.95 / 7.03 ms at 1.5 / 2 / 3) -- and 0.6 for a scene with super-clusters, where a ray from
+// beyond costs next to nothing (its margin rides through the expansion stage) and the margins, which grow with the square of the
+// range times the scene's extent, are what inflates the boxes: C5's scene 7.60 -> 6.96 ms at 64 spp, 53.0 -> 47.1 tests per segment
+// (tools/range_ab.py; 0.5 diagonals are the scene's own bounding sphere, below that the camera rays' culls go).
+constexpr double kRangeOneLevel = 2.0, kRangeTwoLevel = 0.6, kRangeFloor = 0.25;
+// range_diags: ray origins up to this many scene diagonals from the scene's centre use the boxes (>= kRangeFloor)
 void build_clusters(const RtSphere* spheres, uint32_t n, double range_diags, ClusterScene& out);
 
 enum : uint32_t {
