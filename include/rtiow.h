@@ -103,7 +103,7 @@ typedef struct RtParams {
     uint32_t width;      /* full image width                                        */
     uint32_t height;     /* full image height                                       */
     uint32_t spp;        /* samples per pixel (PATH), 1..65536                      */
-    uint32_t max_depth;  /* bounce limit (PATH)                                     */
+    uint32_t max_depth;  /* bounce limit (PATH): 1 .. 524287                        */
     uint32_t seed;       /* RNG seed (PATH)                                         */
     uint32_t mode;       /* RT_MODE_*                                               */
     uint32_t quantiser;  /* RT_QUANT_*                                              */

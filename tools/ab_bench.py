@@ -33,6 +33,7 @@ libs = [(f"{p}:k{k}", lib, h_, k) for p, lib, h_ in libs for k in kernels]
 times = {p: [] for p, _, _, _ in libs}
 tests = {}
 crc = {}
+counts = {}
 for r in range(rounds + 1):
     for path, lib, h_, k in libs:
         prm = V.make_params(w, h, spp=spp, max_depth=50, seed=1, kernel=k, row_block=4, tile_rank=0, tile_count=tileG)
@@ -43,6 +44,7 @@ for r in range(rounds + 1):
             times[path].append(st.kernel_ms)
         crc[path] = int(out.view(np.uint32).sum())
         tests[path] = st.sphere_tests / max(1, st.segments)
+        counts[path] = (st.paths, st.segments, st.sphere_tests)
 for p in times:
     t = times[p]
-    print(f"{os.path.basename(p):40s} median {statistics.median(t):8.3f} ms  min {min(t):8.3f}  frame-sum {crc[p]}  tests/segment {tests[p]:.1f}")
+    print(f"{os.path.basename(p):40s} median {statistics.median(t):8.3f} ms  min {min(t):8.3f}  frame-sum {crc[p]}  tests/segment {tests[p]:.1f}  paths/segments/tests {counts[p]}")

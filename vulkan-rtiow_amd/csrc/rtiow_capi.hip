@@ -481,6 +481,8 @@ int rtRender(RtContext* ctx, const RtCamera* cam, const RtParams* params, void* 
         return fail(ctx, RT_ERR_INVALID, "rtRender: spp must be 1..65536");
     if (params->max_depth == 0)  // (a zero-initialised RtParams; the kernels' bounce loops differ on "no bounce at all")
         return fail(ctx, RT_ERR_INVALID, "rtRender: max_depth must be at least 1");
+    if (params->max_depth > rtiow::kMaxPathDepth)
+        return fail(ctx, RT_ERR_INVALID, "rtRender: max_depth must not exceed 524287");
     if (params->accumulate && (params->sample_offset > 65536u - params->spp))
         return fail(ctx, RT_ERR_INVALID, "rtRender: sample_offset + spp must not exceed 65536");
     if (params->quantiser > RT_QUANT_BOOK) return fail(ctx, RT_ERR_INVALID, "rtRender: unknown quantiser");

@@ -159,6 +159,9 @@ constexpr double kRangeOneLevel = 2.0, kRangeTwoLevel = 0.6, kRangeFloor = 0.25;
 // range_diags: ray origins up to this many scene diagonals from the scene's centre use the boxes (>= kRangeFloor)
 void build_clusters(const RtSphere* spheres, uint32_t n, double range_diags, ClusterScene& out);
 
+// PATH mode: the persistent kernels count a path's segments in 19 bits of its slot's bookkeeping word (rtiow_kernels.hip, Slot)
+constexpr uint32_t kMaxPathDepth = (1u << 19) - 1u;
+
 enum : uint32_t {
     KERNEL_DEFAULT = 0,
     KERNEL_PIXEL = 1,      // one lane per pixel, spp loop inside (v1)

@@ -48,6 +48,12 @@ DI f3 unit3(f3 a) {
     const float k = 1.0f / __builtin_sqrtf(dot3(a, a));
     return mk(a.x * k, a.y * k, a.z * k);
 }
+DI float psqrt(float x);
+DI float pdiv(float a, float b);
+DI f3 unit3_scattered(f3 a) {  // the same for a direction the kernels made themselves (see psqrt)
+    const float k = pdiv(1.0f, psqrt(dot3(a, a)));
+    return mk(a.x * k, a.y * k, a.z * k);
+}
 
 constexpr float kTMin = 0.001f;
 
@@ -73,9 +79,9 @@ DI unsigned long long to_fixed(float x) {
 DI uint32_t resolve_pixel(unsigned long long sr, unsigned long long sg, unsigned long long sb,
                           uint32_t spp, uint32_t quantiser) {
     const float scale = 1.0f / (static_cast<float>(spp) * 4294967296.0f);
-    const float r = __builtin_sqrtf(scale * static_cast<float>(sr));
-    const float g = __builtin_sqrtf(scale * static_cast<float>(sg));
-    const float b = __builtin_sqrtf(scale * static_cast<float>(sb));
+    const float r = psqrt(scale * static_cast<float>(sr));
+    const float g = psqrt(scale * static_cast<float>(sg));
+    const float b = psqrt(scale * static_cast<float>(sb));
     if (quantiser == RT_QUANT_BOOK) return pack_rgb(quant_book(r), quant_book(g), quant_book(b));
     return pack_rgb(quant_unorm8(r), quant_unorm8(g), quant_unorm8(b));
 }
@@ -114,6 +120,59 @@ DI f3 gnormalize(f3 a) {
     const float l = __builtin_sqrtf(gdot(a, a));
     return mk(a.x / l, a.y / l, a.z / l);
 }
+
+// Correctly rounded square root and quotient WITHOUT the range handling hipcc wraps around them (LEAN instantiation).
+// hipcc expands sqrtf(x) into v_sqrt_f32 (1 ulp) and a check of the two neighbouring floats against the residual --
+// after multiplying x by 2^32 when it lies below 2^-96, and with a class test for 0 / inf / NaN at the end: 16
+// instructions, of which the 10 of lean_sqrt are the core; it expands a / b into v_rcp_f32, one Newton step on the reciprocal
+// and three on the quotient between v_div_scale_f32 (which rescales operands whose exponents are extreme or far apart),
+// v_div_fmas_f32 and v_div_fixup_f32 (which put the scale back and deal with 0 / inf / NaN / denormals): 12 instructions,
+// of which the 8 of lean_div are the core.  Where no rescaling happens the full forms ARE the cores, instruction for
+// instruction, so the results are bit-identical: for x == 0 or x >= 2^-96, and for a == 0 or normal a, b with exponents
+// less than 96 apart and a normal quotient.  launch_ch selects the LEAN kernels only for a UBO whose viewport and focal
+// length lie in [2^-20, 2^20]: every square root the shaders take is then 0 or at least 2^-63 (a difference of two
+// numbers of at least 2^-40 in magnitude, or a sum of squares), every divisor between 2^-21 and 2^22, every dividend
+// 0 or at least 2^-44.  (One difference that cannot reach a pixel: -0 / b comes out as +0; each quotient of the shaders
+// is added to 1 or compared with 0 next.)
+DI float lean_sqrt(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = fma_(-s_dn, s, x), r_up = fma_(-s_up, s, x);
+    const float r = (0.0f >= r_dn) ? s_dn : s;
+    return (0.0f < r_up) ? s_up : r;
+}
+DI float lean_div(float a, float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float r1 = fma_(fma_(-b, r0, 1.0f), r0, r0);
+    const float q0 = a * r1;
+    const float q1 = fma_(fma_(-b, q0, a), r1, q0);
+    return fma_(fma_(-b, q1, a), r1, q1);
+}
+
+// PATH mode takes the same lean forms wherever their precondition holds for EVERY input the kernels can see (psqrt, pdiv: 10 and 8
+// instructions instead of 16 and 12; a segment takes a dozen square roots).  Site by site:
+//   * the ray-sphere tests (disc = hb^2 - cc >= +0): lean_sqrt equals sqrtf for disc == 0 and disc >= 2^-96.  Below 2^-96 it may be
+//     off, but any value it can return there lies in [0, 2^-47), like the exact root (< 2^-48), and the root -hb -+ sq is then the
+//     same float either way: for |hb| >= 2^-22 both differ from -hb by less than half an ulp of hb (2^-46 at least) and round to -hb;
+//     for |hb| < 2^-22 both roots are below 2^-21 < t_min = 0.001 and the sphere is no hit.  NaN, negative, -0 and +inf arguments come
+//     out as from sqrtf (NaN, NaN, -0, +inf): the instruction's own results, which no comparison of the correction step replaces;
+//   * random_unit_vector: 1 - z^2 with z = 1 - 2u, u a multiple of 2^-24 in [0, 1): 0 or at least 2^-23; the lens: sqrt(u), 0 or >= 2^-24;
+//   * dielectric: 1 - cos^2 with cos <= 1 a float: 0, negative (-> NaN both ways) or a multiple of 2^-48 not below 2^-25;
+//     |1 - dot(perp, perp)|: 1 - x is exact for a float x in [0.5, 2] and a multiple of 2^-24, below 0.5 it is >= 0.5;
+//   * unit3 of a SCATTERED direction: lambertian directions have a component of at least 1e-8 in magnitude (the near-zero rule replaces
+//     the others by the normal), so dot >= 1e-16 and its root lies in [1e-8, 4): divisor and dividend (1.0) are normal, 27 binades
+//     apart at most; a metal or glass direction is a reflection or refraction of a unit vector (length 1 to a few ulps), a fuzzed one the
+//     sum of a unit vector and fuzz <= 1 times another, which comes out exactly 0 (absorbed before unit3: dir . n > 0 fails) or with a
+//     component of at least 2^-25 unless all three cancel to within 2^-48 of their operands at once -- 2^-72 of the fuzzed samples
+//     would have to; such a sample may differ from the oracle in its last bits.  unit3 of a CAMERA ray keeps hipcc's forms: its length is
+//     whatever the caller's camera makes it;
+//   * resolve_pixel: scale * sum with scale >= 2^-48 and sum an integer: 0 or >= 2^-48.
+// -DRTIOW_LEAN_PATH=0: hipcc's forms everywhere (A/B and a parity check of the above: the frames are the same).
+#ifndef RTIOW_LEAN_PATH
+#define RTIOW_LEAN_PATH 1
+#endif
+DI float psqrt(float x) { return RTIOW_LEAN_PATH ? lean_sqrt(x) : __builtin_sqrtf(x); }
+DI float pdiv(float a, float b) { return RTIOW_LEAN_PATH ? lean_div(a, b) : a / b; }
 
 #ifndef RTIOW_TU_SMALL_CLUSTERED
 // ch_kernel_tiles: the shaders as the reference dispatches them -- 16x16 workgroup as raytrace06.comp:2, one lane per
@@ -247,39 +306,11 @@ DI uint32_t ch_unorm8(float x) {
     return BOUNDED ? q : (q < 255u ? q : 255u);
 }
 
-// Correctly rounded square root and quotient WITHOUT the range handling hipcc wraps around them (LEAN instantiation).
-// hipcc expands sqrtf(x) into v_sqrt_f32 (1 ulp) and a check of the two neighbouring floats against the residual --
-// after multiplying x by 2^32 when it lies below 2^-96, and with a class test for 0 / inf / NaN at the end: 16
-// instructions, of which the 10 of ch_sqrt are the core; it expands a / b into v_rcp_f32, one Newton step on the reciprocal
-// and three on the quotient between v_div_scale_f32 (which rescales operands whose exponents are extreme or far apart),
-// v_div_fmas_f32 and v_div_fixup_f32 (which put the scale back and deal with 0 / inf / NaN / denormals): 12 instructions,
-// of which the 8 of ch_div are the core.  Where no rescaling happens the full forms ARE the cores, instruction for
-// instruction, so the results are bit-identical: for x == 0 or x >= 2^-96, and for a == 0 or normal a, b with exponents
-// less than 96 apart and a normal quotient.  launch_ch selects the LEAN kernels only for a UBO whose viewport and focal
-// length lie in [2^-20, 2^20]: every square root the shaders take is then 0 or at least 2^-63 (a difference of two
-// numbers of at least 2^-40 in magnitude, or a sum of squares), every divisor between 2^-21 and 2^22, every dividend
-// 0 or at least 2^-44.  (One difference that cannot reach a pixel: -0 / b comes out as +0; each quotient of the shaders
-// is added to 1 or compared with 0 next.)
-DI float ch_sqrt(float x) {
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
-    const float r_dn = fma_(-s_dn, s, x), r_up = fma_(-s_up, s, x);
-    const float r = (0.0f >= r_dn) ? s_dn : s;
-    return (0.0f < r_up) ? s_up : r;
-}
-DI float ch_div(float a, float b) {
-    const float r0 = __builtin_amdgcn_rcpf(b);
-    const float r1 = fma_(fma_(-b, r0, 1.0f), r0, r0);
-    const float q0 = a * r1;
-    const float q1 = fma_(fma_(-b, q0, a), r1, q0);
-    return fma_(fma_(-b, q1, a), r1, q1);
-}
-
 // one pixel: raytrace06.comp:21-48 / raytrace05.comp:21-40 from the hoisted products (xx = dir.x*dir.x, ox = oc.x*dir.x, ...)
 template <bool LEAN>
 DI uint32_t ch_pixel(uint32_t mode, const ChConst& k, float dx, float xx, float ox, float dy, float yy, float oy) {
-    auto sqrt_ = [](float x) { return LEAN ? ch_sqrt(x) : __builtin_sqrtf(x); };
-    auto div_ = [](float a, float b) { return LEAN ? ch_div(a, b) : a / b; };
+    auto sqrt_ = [](float x) { return LEAN ? lean_sqrt(x) : __builtin_sqrtf(x); };
+    auto div_ = [](float a, float b) { return LEAN ? lean_div(a, b) : a / b; };
     const float qa = (xx + yy) + k.zz;             // gdot(dir, dir)
     // 2 * gdot(oc, dir).  oc = origin - centre = (+0, +0, 1) by the shader's constants, so oc.x * dir.x and oc.y * dir.y are zeros
     // of either sign for the finite dir.x, dir.y of a frame with finite UBO values, their sum is a zero, and a zero plus
@@ -403,7 +434,7 @@ DI f3 random_unit_vector(Pcg& rng) {
     const float u1 = rng.uniform();
     const float u2 = rng.uniform();
     const float z = 1.0f - 2.0f * u1;
-    const float r = __builtin_sqrtf(fma_(-z, z, 1.0f));
+    const float r = psqrt(fma_(-z, z, 1.0f));
     float c, s;
     sincos_2pi(u2, c, s);
     return mk(r * c, r * s, z);
@@ -422,7 +453,7 @@ DI void camera_path(const PathArgs& a, uint32_t i, uint32_t j, uint32_t sample, 
     if (c.lens_radius > 0.0f) {  // wave-uniform; random_in_unit_disk: radius sqrt(u1), azimuth 2 pi u2
         const float u1 = p.rng.uniform();
         const float u2 = p.rng.uniform();
-        const float r = __builtin_sqrtf(u1);
+        const float r = psqrt(u1);
         float cs, sn;
         sincos_2pi(u2, cs, sn);
         const float rdx = c.lens_radius * (r * cs), rdy = c.lens_radius * (r * sn);
@@ -478,7 +509,7 @@ DI bool scatter(f3 ctr, const ShadeRec& m, float s, Path& p) {
         const float ratio = front ? (1.0f / m.param) : m.param;  // ior
         const float nd = -dot3(p.du, n);
         const float cosv = (nd < 1.0f) ? nd : 1.0f;
-        const float sinv = __builtin_sqrtf(fma_(-cosv, cosv, 1.0f));
+        const float sinv = psqrt(fma_(-cosv, cosv, 1.0f));
         bool reflect = ratio * sinv > 1.0f;
         if (!reflect) {  // Schlick; (1-cos)^5 by repeated multiply, never powf
             float r0 = (1.0f - ratio) / (1.0f + ratio);
@@ -495,12 +526,12 @@ DI bool scatter(f3 ctr, const ShadeRec& m, float s, Path& p) {
         } else {
             const f3 perp = mk(ratio * fma_(cosv, n.x, p.du.x), ratio * fma_(cosv, n.y, p.du.y),
                                ratio * fma_(cosv, n.z, p.du.z));
-            const float par = -__builtin_sqrtf(__builtin_fabsf(1.0f - dot3(perp, perp)));
+            const float par = -psqrt(__builtin_fabsf(1.0f - dot3(perp, perp)));
             dir = mk(fma_(par, n.x, perp.x), fma_(par, n.y, perp.y), fma_(par, n.z, perp.z));
         }
     }
     p.o = hit;
-    p.du = unit3(dir);
+    p.du = unit3_scattered(dir);
     return true;
 }
 
@@ -530,7 +561,7 @@ DI int closest_hit_simple(const float4* lds, uint32_t n, const Path& p, float& b
         const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
         const float disc = fma_(hb, hb, -cc);
         if (__builtin_signbit(disc) || disc != disc) continue;
-        const float sq = __builtin_sqrtf(disc);
+        const float sq = psqrt(disc);
         float root = -hb - sq;
         if (!(root > kTMin && root < best)) {
             root = -hb + sq;
@@ -703,13 +734,22 @@ constexpr uint32_t kWaveLineBytes = kLineBufs * (kChunkPix + kLineMetaWords) * 4
 constexpr uint32_t kAccEntries = 64;                 // pixels a wave may have in flight
 constexpr uint32_t kAccWords = 4;                    // u64 words per entry: r, g, b, samples done
 constexpr uint32_t kWaveAccBytes = kAccEntries * kAccWords * 8u;  // 2 KiB of LDS per wave
+constexpr uint32_t kWavePixBytes = kAccEntries * 4u;              // ... and the pixel of each entry
 
+// Bookkeeping of a path in flight, ONE register: its pixel's accumulator entry, numbered across the workgroup (wave * kAccEntries +
+// index: 10 bits), the line buffer of its chunk + 1 (0: the pixel goes straight to the frame: 3 bits) and the segments it has taken
+// (19 bits: rtRender caps max_depth accordingly).  The pixel itself is looked up by the entry when it completes (lds_pix: one word per
+// accumulator entry, written when the pixel is opened).  Rounds 1-3 carried pixel, entry, line and depth in a register each, eight
+// per lane -- the first place to look when the four-waves variant spilled 28.
+constexpr uint32_t kMetaLineShift = 10, kMetaDepthShift = 13;
+static_assert(kMaxPathDepth == (1u << (32u - kMetaDepthShift)) - 1u, "rtRender's cap on max_depth is the depth field of Slot::meta");
+DI uint32_t meta_of(uint32_t entry, uint32_t line) { return entry | (line << kMetaLineShift); }
+DI uint32_t meta_entry(uint32_t m) { return m & ((1u << kMetaLineShift) - 1u); }
+DI uint32_t meta_line(uint32_t m) { return (m >> kMetaLineShift) & 7u; }
+DI uint32_t meta_depth(uint32_t m) { return m >> kMetaDepthShift; }
 struct Slot {
     Path p;
-    uint32_t pix;    // local pixel of the path in flight
-    uint32_t entry;  // its accumulator entry, numbered across the workgroup: wave * kAccEntries + index
-    uint32_t line;   // line buffer of its chunk + 1; 0: the pixel goes straight to the frame
-    uint32_t depth;
+    uint32_t meta;
     bool active;
 };
 
@@ -746,7 +786,7 @@ DI void examine_candidate(const float4* lds, uint32_t j, uint32_t n, const Path&
     const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
     const float disc = fma_(hb, hb, -cc);
     if (__builtin_signbit(disc) || disc != disc) return;
-    const float sq = __builtin_sqrtf(disc);
+    const float sq = psqrt(disc);
     float root = -hb - sq;
     if (!(root > kTMin && root < best)) {
         root = -hb + sq;
@@ -861,7 +901,7 @@ DI void trace_sparse(const float4* list, const uint32_t* idx_map, uint32_t n_slo
                 const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
                 const float disc = fma_(hb, hb, -cc);
                 const bool cand = !__builtin_signbit(disc) && disc == disc && orig < n;
-                const float sq = __builtin_sqrtf(cand ? disc : 0.0f);
+                const float sq = psqrt(cand ? disc : 0.0f);
                 float root = -hb - sq;
                 root = root > kTMin ? root : -hb + sq;
                 const unsigned long long k2 = (static_cast<unsigned long long>(__float_as_uint(root)) << 32) | orig;
@@ -907,7 +947,7 @@ DI void examine_keyed(const float4* slots, const uint32_t* idx_map, uint32_t slo
     const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
     const float disc = fma_(hb, hb, -cc);
     if (__builtin_signbit(disc) || disc != disc) return;
-    const float sq = __builtin_sqrtf(disc);
+    const float sq = psqrt(disc);
     float root = -hb - sq;
     root = root > kTMin ? root : -hb + sq;
     if (!(root > kTMin)) return;
@@ -1243,7 +1283,7 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
                     const float hb = fma_(ocz, p.du.z, fma_(ocy, p.du.y, ocx * p.du.x));
                     const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
                     const float disc = fma_(hb, hb, -cc);
-                    const float sq = __builtin_sqrtf(disc);
+                    const float sq = psqrt(disc);
                     float root = -hb - sq;
                     root = root > kTMin ? root : -hb + sq;
                     const bool hit = static_cast<int32_t>(__float_as_uint(disc)) >= 0 && root > kTMin;
@@ -1758,7 +1798,7 @@ DI void examine_loaded(const float4& s, uint32_t orig, uint32_t slot, const Spar
     const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
     const float disc = fma_(hb, hb, -cc);
     if (__builtin_signbit(disc) || disc != disc) return;
-    const float sq = __builtin_sqrtf(disc);
+    const float sq = psqrt(disc);
     float root = -hb - sq;
     root = root > kTMin ? root : -hb + sq;
     if (!(root > kTMin)) return;
@@ -1919,10 +1959,7 @@ DI void compact_to_slot0(Slot (&sl)[R], uint32_t* scratch) {
         rec[3] = q.p.du.x; rec[4] = q.p.du.y; rec[5] = q.p.du.z;
         rec[6] = q.p.att.x; rec[7] = q.p.att.y; rec[8] = q.p.att.z;
         rec[9] = __uint_as_float(q.p.rng.state);
-        rec[10] = __uint_as_float(q.depth);
-        rec[11] = __uint_as_float(q.pix);
-        rec[12] = __uint_as_float(q.entry);
-        rec[13] = __uint_as_float(q.line);
+        rec[10] = __uint_as_float(q.meta);
         q.active = false;
     }
     const uint32_t k = lane_rank(idle0);
@@ -1933,10 +1970,7 @@ DI void compact_to_slot0(Slot (&sl)[R], uint32_t* scratch) {
         q.p.du = mk(rec[3], rec[4], rec[5]);
         q.p.att = mk(rec[6], rec[7], rec[8]);
         q.p.rng = Pcg(__float_as_uint(rec[9]));
-        q.depth = __float_as_uint(rec[10]);
-        q.pix = __float_as_uint(rec[11]);
-        q.entry = __float_as_uint(rec[12]);
-        q.line = __float_as_uint(rec[13]);
+        q.meta = __float_as_uint(rec[10]);
         q.active = true;
     }
 }
@@ -1966,7 +2000,7 @@ DI void compact_to_slot0(Slot (&sl)[R], uint32_t* scratch) {
 // inflated for the exact test's own rounding (rtiow_clusters.cpp), for origins within their range: launch_path
 // switches the cull off (every cluster, every ray) for a camera whose lens leaves that range.
 constexpr uint32_t kPassSpans = 2;  // spans of consecutive pixels (of one row) a pass hands out at most: one per half of the wave
-constexpr uint32_t kPassRecBytes = 48;  // one waiting camera path: origin, direction, attenuation, RNG, pixel, entry | line
+constexpr uint32_t kPassRecBytes = 48;  // one waiting camera path: origin, direction, attenuation, RNG, entry | line | depth
 #ifndef RTIOW_PASS_KEEP
 #define RTIOW_PASS_KEEP 32  // records a wave keeps beyond its idle slots: a pass then runs on min(64, idle + 32) lanes
 #endif
@@ -2072,7 +2106,7 @@ DI void exact_keyed_lockstep(const float4* slots, const uint32_t* idx_map, uint3
     const float hb = fma_(ocz, p.du.z, fma_(ocy, p.du.y, ocx * p.du.x));
     const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
     const float disc = fma_(hb, hb, -cc);
-    const float sq = __builtin_sqrtf(disc);
+    const float sq = psqrt(disc);
     float root = -hb - sq;
     root = root > kTMin ? root : -hb + sq;
     // (a discriminant that is negative, -0 or NaN gives no hit, as in examine_keyed)
@@ -2254,19 +2288,19 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     unsigned long long* lds_acc = reinterpret_cast<unsigned long long*>(lds_shade + (SHADE_LDS ? 2u * a.n : 0u));
     const uint32_t waves_in_group = blockDim.x / 64u;
     const uint32_t wave_in_group = threadIdx.x / 64u;
+    // per accumulator entry: the pixel it belongs to (indexed like the entries, across the workgroup)
+    uint32_t* lds_pix = reinterpret_cast<uint32_t*>(lds_acc + waves_in_group * (kWaveAccBytes / 8u));
+    unsigned char* lds_per_wave = reinterpret_cast<unsigned char*>(lds_pix) + waves_in_group * kWavePixBytes;
     // per wave: the line buffers of the chunks it is assembling
-    uint32_t* lds_line = reinterpret_cast<uint32_t*>(lds_acc + waves_in_group * (kWaveAccBytes / 8u)) +
-                         wave_in_group * (kWaveLineBytes / 4u);
+    uint32_t* lds_line = reinterpret_cast<uint32_t*>(lds_per_wave) + wave_in_group * (kWaveLineBytes / 4u);
     uint32_t* lds_line_meta = lds_line + kLineBufs * kChunkPix;  // per buffer {pixels done, pixels expected, cost (u64)}
     // (ACCEL) per wave: the phase-2 work list and result keys of trace_clustered
     [[maybe_unused]] unsigned long long* lds_results = reinterpret_cast<unsigned long long*>(
-        reinterpret_cast<unsigned char*>(lds_acc + waves_in_group * (kWaveAccBytes / 8u)) +
-        waves_in_group * kWaveLineBytes + wave_in_group * wave_item_bytes(a.n_super != 0u));
+        lds_per_wave + waves_in_group * kWaveLineBytes + wave_in_group * wave_item_bytes(a.n_super != 0u));
     [[maybe_unused]] uint16_t* lds_items = reinterpret_cast<uint16_t*>(lds_results + 128);
     // (ACCEL) per wave: pass_keep records of camera paths waiting for a slot (three float4 each)
     [[maybe_unused]] float4* lds_pbuf = reinterpret_cast<float4*>(
-        reinterpret_cast<unsigned char*>(lds_acc + waves_in_group * (kWaveAccBytes / 8u)) +
-        waves_in_group * (kWaveLineBytes + wave_item_bytes(a.n_super != 0u)) + wave_in_group * g.pass_keep * kPassRecBytes);
+        lds_per_wave + waves_in_group * (kWaveLineBytes + wave_item_bytes(a.n_super != 0u)) + wave_in_group * g.pass_keep * kPassRecBytes);
     if (ACCEL) {
         for (uint32_t i = threadIdx.x; i < g.n_pad; i += blockDim.x) {
             lds_spheres[i] = a.cslots[i];
@@ -2291,7 +2325,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
 #pragma unroll
     for (int r = 0; r < kSlots; ++r) {
         sl[r].active = false;
-        sl[r].pix = sl[r].entry = sl[r].line = sl[r].depth = 0u;
+        sl[r].meta = 0u;
         sl[r].p.o = sl[r].p.du = sl[r].p.att = mk(0.0f, 0.0f, 0.0f);
     }
     // wave-uniform queue state (SGPRs)
@@ -2345,7 +2379,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         bool finished = false;
         if (q.active) {
             ++n_segments;
-            unsigned long long* acc = lds_acc + q.entry * kAccWords;
+            unsigned long long* acc = lds_acc + meta_entry(q.meta) * kAccWords;
             if (hit_slot < 0) {
                 const f3 rad = sky_radiance(q.p);
                 atomicAdd(acc + 0, to_fixed(rad.x));  // ds_add_u64: order-independent integer sum
@@ -2365,8 +2399,9 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 }
                 if (!scatter(mk(geo.x, geo.y, geo.z), m, hit_t, q.p)) {
                     finished = true;  // absorbed: radiance 0
-                } else if (++q.depth >= a.max_depth) {
-                    finished = true;  // depth exhausted: radiance 0
+                } else {
+                    q.meta += 1u << kMetaDepthShift;
+                    if (meta_depth(q.meta) >= a.max_depth) finished = true;  // depth exhausted: radiance 0
                 }
             }
         }
@@ -2375,29 +2410,31 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         // this wave (or serialised within this one), so the sums it reads are final.
         bool completed = false;
         bool line_full = false;  // this lane's pixel was the last of a line buffer
+        uint32_t done_pix = 0u;  // the pixel this lane's sample completed
         if (finished) {
 #ifdef RTIOW_DEBUG_TIMELINE
-            if (tl_dry != 0ull && q.depth + 1u > tl_deepest) tl_deepest = q.depth + 1u;
-            if (q.depth + 1u >= 40u) tl_deep_end = wall_clock64();
+            if (tl_dry != 0ull && meta_depth(q.meta) + 1u > tl_deepest) tl_deepest = meta_depth(q.meta) + 1u;
+            if (meta_depth(q.meta) + 1u >= 40u) tl_deep_end = wall_clock64();
 #endif
             q.active = false;
-            unsigned long long* acc = lds_acc + q.entry * kAccWords;
+            unsigned long long* acc = lds_acc + meta_entry(q.meta) * kAccWords;
             // low half: samples done; high half: the segments they took (<= 65535 each, <= 65536 samples)
             // (A long path counts kLongWeight-fold: what ends a frame is not the work of its last chunks but the LENGTH of
             // the paths born in them -- fifty bounces at one iteration each -- so chunks in which long paths occur are to go
             // out first whatever their average; the sum only orders the chunks of the next frame.)
-            const uint32_t segs1 = q.depth < 0xFFFEu ? q.depth + 1u : 0xFFFFu;
+            const uint32_t segs1 = meta_depth(q.meta) < 0xFFFEu ? meta_depth(q.meta) + 1u : 0xFFFFu;
             const uint32_t segs = segs1 > kLongFrom ? (segs1 * kLongWeight < 0xFFFFu ? segs1 * kLongWeight : 0xFFFFu) : segs1;
             const unsigned long long before = atomicAdd(acc + 3, 1ull | (static_cast<unsigned long long>(segs) << 32));
             if (static_cast<uint32_t>(before) + 1u == a.spp) {
                 completed = true;
-                const uint32_t colour = close_pixel(a, q.pix, acc[0], acc[1], acc[2]);
-                const uint32_t line = q.line;
+                done_pix = lds_pix[meta_entry(q.meta)];  // (written when the pixel was opened: hand_out)
+                const uint32_t colour = close_pixel(a, done_pix, acc[0], acc[1], acc[2]);
+                const uint32_t line = meta_line(q.meta);
                 if (line == 0u) {
-                    const uint32_t lr = q.pix / a.width, i = q.pix - lr * a.width;
+                    const uint32_t lr = done_pix / a.width, i = done_pix - lr * a.width;
                     a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = colour;
                 } else {  // a pixel of a chunk this wave renders alone: into the line buffer
-                    lds_line[(line - 1u) * kChunkPix + q.pix % kChunkPix] = colour;
+                    lds_line[(line - 1u) * kChunkPix + done_pix % kChunkPix] = colour;
                     uint32_t* meta = lds_line_meta + kLineMetaWords * (line - 1u);
                     atomicAdd(reinterpret_cast<unsigned long long*>(meta + 2), (before >> 32) + segs);  // the chunk's cost, in LDS
                     const uint32_t done = atomicAdd(meta, 1u);
@@ -2410,9 +2447,9 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 if (a.chunk_cost != nullptr && line == 0u) {
                     const unsigned long long cost = (before >> 32) + segs;
                     if (cost >= static_cast<unsigned long long>(a.spp) * kLongFrom + kLongFrom * kLongWeight)  // (one long path at least)
-                        atomicAdd(a.chunk_cost + q.pix / kChunkPix, cost);
-                    else if ((q.pix & 3u) == 0u)
-                        atomicAdd(a.chunk_cost + q.pix / kChunkPix, 4ull * cost);
+                        atomicAdd(a.chunk_cost + done_pix / kChunkPix, cost);
+                    else if ((done_pix & 3u) == 0u)
+                        atomicAdd(a.chunk_cost + done_pix / kChunkPix, 4ull * cost);
                 }
             }
         }
@@ -2423,11 +2460,11 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         while (done_mask != 0ull) {
             const int l = __builtin_ctzll(done_mask);
             done_mask &= done_mask - 1ull;
-            const uint32_t e = __builtin_amdgcn_readlane(q.entry, l);
-            free_entries |= 1ull << (e % kAccEntries);
+            const uint32_t m = __builtin_amdgcn_readlane(q.meta, l);
+            free_entries |= 1ull << (meta_entry(m) % kAccEntries);
             if (__builtin_amdgcn_readlane(static_cast<uint32_t>(line_full), l) != 0u) {
-                const uint32_t line = __builtin_amdgcn_readlane(q.line, l) - 1u;
-                const uint32_t first = __builtin_amdgcn_readlane(q.pix, l) / kChunkPix * kChunkPix;
+                const uint32_t line = meta_line(m) - 1u;
+                const uint32_t first = __builtin_amdgcn_readlane(done_pix, l) / kChunkPix * kChunkPix;
                 const uint32_t count = g.total_pix - first < kChunkPix ? g.total_pix - first : kChunkPix;
                 if (lane < count) {
                     const uint32_t pix = first + lane;
@@ -2578,6 +2615,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     ++pool_next;
                     cur_s = 0u;
                     if (lane < kAccWords) lds_acc[(wave_in_group * kAccEntries + cur_entry) * kAccWords + lane] = 0ull;
+                    if (lane == kAccWords) lds_pix[wave_in_group * kAccEntries + cur_entry] = pix;
                 }
                 const uint32_t n = want - served < a.spp - cur_s ? want - served : a.spp - cur_s;
                 if (!on_range(served, n, cur_pix, wave_in_group * kAccEntries + cur_entry, cur_s)) break;  // (the pixel stays open)
@@ -2609,7 +2647,8 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     if (!SHADE_LDS && n_idle < g.pass_min_idle && __ballot(sl[0].active || sl[kSlots - 1].active) != 0ull) break;
                     Slot ps;
                     ps.active = false;
-                    ps.pix = ps.entry = ps.line = ps.depth = 0u;
+                    ps.meta = 0u;
+                    uint32_t gen_pix = 0u;
                     ps.p.o = ps.p.du = ps.p.att = mk(0.0f, 0.0f, 0.0f);
                     uint32_t gen_s = 0u;
                     // the spans of consecutive pixels (of one row) the pass hands out: wave-uniform
@@ -2632,9 +2671,8 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                         }
                         last_pix = pix;
                         if (lane - first < n) {  // (unsigned: first <= lane < first + n)
-                            ps.pix = pix;
-                            ps.entry = entry;
-                            ps.line = cur_line;
+                            gen_pix = pix;
+                            ps.meta = meta_of(entry, cur_line);
                             gen_s = s0 + (lane - first);
                         }
                         return true;
@@ -2645,7 +2683,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     DBG_ADD(dbg_pass[1], lane == 0u ? granted : 0u);
                     ps.active = lane < granted;
                     if (ps.active) {
-                        const uint32_t lr = ps.pix / a.width, i = ps.pix - lr * a.width;
+                        const uint32_t lr = gen_pix / a.width, i = gen_pix - lr * a.width;
                         const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
                         camera_path(a, i, j, a.sample_offset + gen_s, ps.p);
                         ++n_paths;
@@ -2672,8 +2710,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                         float4* rec = record(lane_rank(going));
                         rec[0] = make_float4(ps.p.o.x, ps.p.o.y, ps.p.o.z, ps.p.du.x);
                         rec[1] = make_float4(ps.p.du.y, ps.p.du.z, ps.p.att.x, ps.p.att.y);
-                        rec[2] = make_float4(ps.p.att.z, __uint_as_float(ps.p.rng.state), __uint_as_float(ps.pix),
-                                             __uint_as_float(ps.entry | (ps.line << 16)));
+                        rec[2] = make_float4(ps.p.att.z, __uint_as_float(ps.p.rng.state), __uint_as_float(ps.meta), 0.0f);  // (depth 1)
                     }
                     if (pass_n == 0u) continue;  // every ray left the scene (sky): the slots are as idle as before
                 }
@@ -2693,10 +2730,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                         q.p.du = mk(r0.w, r1.x, r1.y);
                         q.p.att = mk(r1.z, r1.w, r2.x);
                         q.p.rng = Pcg(__float_as_uint(r2.y));
-                        q.pix = __float_as_uint(r2.z);
-                        q.entry = __float_as_uint(r2.w) & 0xFFFFu;
-                        q.line = __float_as_uint(r2.w) >> 16;
-                        q.depth = 1u;
+                        q.meta = __float_as_uint(r2.z);
                         q.active = true;
                     }
                 }
@@ -2733,9 +2767,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
 #pragma unroll
                         for (int r = 0; r < kSlots; ++r)
                             if (!sl[r].active && my_idx[r] - first < n) {
-                                sl[r].pix = pix;
-                                sl[r].entry = entry;
-                                sl[r].line = cur_line;
+                                sl[r].meta = meta_of(entry, cur_line);  // (depth 0)
                                 got[r] = true;
                             }
                         return true;
@@ -2758,7 +2790,6 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                             q.p.du = mk(r0.w, r1.x, r1.y);
                             q.p.rng = Pcg(__float_as_uint(r1.z));
                             q.p.att = mk(1.0f, 1.0f, 1.0f);
-                            q.depth = 0u;
                             q.active = true;
                             ++n_paths;
                         }
@@ -2775,23 +2806,21 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 Slot& q = sl[r];
                 const unsigned long long mask = r == 0 ? idle0 : idle1;
                 const uint32_t rank = lane_rank(mask);
-                uint32_t my_s = 0u;
+                uint32_t my_s = 0u, my_pix = 0u;
                 bool got_sample = false;
                 hand_out(static_cast<uint32_t>(__popcll(mask)), [&](uint32_t first, uint32_t n, uint32_t pix, uint32_t entry, uint32_t s0) {
                     if (!q.active && rank - first < n) {
-                        q.pix = pix;
-                        q.entry = entry;
-                        q.line = cur_line;
+                        my_pix = pix;
+                        q.meta = meta_of(entry, cur_line);  // (depth 0)
                         my_s = s0 + (rank - first);
                         got_sample = true;
                     }
                     return true;
                 });
                 if (got_sample) {  // start the sample
-                    const uint32_t lr = q.pix / a.width, i = q.pix - lr * a.width;
+                    const uint32_t lr = my_pix / a.width, i = my_pix - lr * a.width;
                     const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
                     camera_path(a, i, j, a.sample_offset + my_s, q.p);
-                    q.depth = 0u;
                     q.active = true;
                     ++n_paths;
                 }
@@ -3155,9 +3184,9 @@ __global__ __launch_bounds__(1024) void order_chunks_kernel(unsigned long long* 
 // file (Makefile: -DRTIOW_TU_SMALL_CLUSTERED, object rtiow_kernels_small.o) with a scheduler and a register budget of their
 // own.  Round 2: -mllvm -amdgpu-sched-strategy=iterative-ilp, 159 registers, three waves per SIMD (cover frame 8.64 -> 8.40
 // ms against the default scheduler).  Round 3: iterative-minreg brings the flat-axis variant to 136 registers; held to 128
-// (-DRTIOW_SMALL_WAVES_PER_EU=4) it spills 13 of them and runs FOUR waves per SIMD -- launch_path then finds two groups of
-// 512 threads per CU: cover frame 7.95 -> 7.19 ms, one eighth of it 1.33 -> 1.26 (interleaved A/B, tools/ab_bench.py;
-// iterative-minreg at three waves: 8.48).  The large-scene variants spill 115 registers at 128 and have no LDS for sixteen
+// (-DRTIOW_SMALL_WAVES_PER_EU=4) it spilled 13 of them (28 by the end of the round) and runs FOUR waves per SIMD -- launch_path
+// then finds two groups of 512 threads per CU: cover frame 7.95 -> 7.19 ms, one eighth of it 1.33 -> 1.26 (interleaved A/B,
+// tools/ab_bench.py; iterative-minreg at three waves: 8.48).  Round 4: with Slot's bookkeeping in one register, 4 spilled.  The large-scene variants spill 115 registers at 128 and have no LDS for sixteen
 // waves' buffers, the flat-list kernels (95 registers) gain nothing: they stay with the default scheduler.
 #ifdef RTIOW_TU_SMALL_CLUSTERED
 PersistentKernelFn small_clustered_kernel(bool flat) {
@@ -3187,7 +3216,7 @@ hipError_t launch_ch(const ChArgs& args, hipStream_t stream) {
     a.rows_per_wave = rpw;
     a.vector_store = (reinterpret_cast<uintptr_t>(a.dst) % 16u == 0u && a.dst_stride % 4u == 0u) ? 1u : 0u;
     const uint32_t blocks = tiles_x * ((a.height + 4u * rpw - 1u) / (4u * rpw));
-    // the lean square roots and quotients (ch_sqrt, ch_div) for a camera of moderate proportions, hipcc's full forms otherwise
+    // the lean square roots and quotients (lean_sqrt, lean_div) for a camera of moderate proportions, hipcc's full forms otherwise
     auto moderate = [](float v) { return std::fabs(v) >= 0x1p-20f && std::fabs(v) <= 0x1p20f; };
     const bool lean = moderate(a.ubo.viewportWidth) && moderate(a.ubo.viewportHeight) && moderate(a.ubo.focalLength) &&
                       !getenv("RTIOW_DEBUG_CH_FULL");  // (the variable: A/B and parity tests)
@@ -3289,7 +3318,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     const uint32_t box_bytes = flat ? 16u : 32u;  // (LDS per box: without the flat axis one float4 instead of two)
     auto clustered_fits = [&](uint32_t n_super) {
         return static_cast<size_t>(a.n_cslots) * 20u + static_cast<size_t>(a.n_clusters + n_super) * box_bytes +
-                   4u * (kWaveAccBytes + kWaveLineBytes + wave_item_bytes(n_super != 0u)) <= kLdsPerCu;  // at least one 256-thread group
+                   4u * (kWaveAccBytes + kWavePixBytes + kWaveLineBytes + wave_item_bytes(n_super != 0u)) <= kLdsPerCu;  // at least one 256-thread group
     };
     if (accel && !clustered_fits(a.n_super)) a.n_super = 0u;
     if (accel && !clustered_fits(0u)) accel = false;
@@ -3322,7 +3351,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // the clustered kernels' primary pass keeps up to pass_keep camera paths per wave in LDS records of their own; a
     // large scene with no room for them (C5: one 768-thread group beside 92 KB of list) does without -- its passes then
     // make no more paths than there are idle slots, and the records sit in the two-level work-list area alone
-    auto wave_bytes = [&](uint32_t keep) { return kWaveAccBytes + kWaveLineBytes + (accel ? item_bytes + keep * kPassRecBytes : 0u); };
+    auto wave_bytes = [&](uint32_t keep) { return kWaveAccBytes + kWavePixBytes + kWaveLineBytes + (accel ? item_bytes + keep * kPassRecBytes : 0u); };
     void (*kernel_fn)(PathArgs, PersistArgs) =
         accel ? (shade_lds ? small_clustered_kernel(flat) : (flat ? path_persistent_kernel<false, true, true> : path_persistent_kernel<false, true, false>))
               : (shade_lds ? path_persistent_kernel<true, false> : path_persistent_kernel<false, false>);
