@@ -218,7 +218,14 @@ int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materi
             if (!(fz > 0.0f)) fz = 0.0f;
             r.param = fz;
         } else if (m.kind == RT_MAT_DIELECTRIC) {
+            // glass has no albedo: its record carries the two quotients scatter() needs instead -- 1 / ior and Schlick's
+            // (1 - ratio) / (1 + ratio) for either side -- by the oracle's own IEEE single operations (24 instructions
+            // off the kernels' glass branch)
             r.param = m.ior;
+            const float inv = 1.0f / m.ior;
+            r.albedo[0] = inv;
+            r.albedo[1] = (1.0f - inv) / (1.0f + inv);      // front face: ratio = 1 / ior
+            r.albedo[2] = (1.0f - m.ior) / (1.0f + m.ior);  // back face: ratio = ior
         }
         r.inv_r = 1.0f / spheres[i].radius;  // IEEE single division, as the oracle's
     }
@@ -590,6 +597,10 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
                         c.pass_stats[0], double(c.pass_stats[1]) / c.pass_stats[0], double(c.pass_stats[2]) / c.pass_stats[0],
                         double(c.pass_stats[3]) / c.pass_stats[0], double(c.pass_stats[4]) / c.pass_stats[0],
                         double(c.pass_stats[4] - c.pass_stats[5]) / c.pass_stats[0] , double(c.pass_stats[5]) / c.pass_stats[0]);
+            if (c.pass_stats[0])
+                fprintf(stderr, "   per pass: handing out %.0f cycles, camera %.0f; records -> slots %.0f cycles each, %.2f times per pass\n",
+                        double(c.pass_stats[6]) / c.pass_stats[0], double(c.pass_stats[7]) / c.pass_stats[0],
+                        c.pass_stats[9] ? double(c.pass_stats[8]) / c.pass_stats[9] : 0.0, double(c.pass_stats[9]) / c.pass_stats[0]);
             if (c.tail_iters)
                 fprintf(stderr, "tail iteration, shader cycles: refill+merge %.0f trace %.0f shade %.0f\n",
                         double(c.tail_cyc[0]) / c.tail_iters, double(c.tail_cyc[1]) / c.tail_iters,

@@ -33,7 +33,8 @@ struct Counters {
     unsigned long long tail_iters, tail_ticks;  // diagnostic builds: iterations / 100 MHz ticks of all waves after running dry
     unsigned long long tail_sparse_iters, tail_sparse_ticks, tail_sparse_paths;  // the sparse ones among them
     unsigned long long tail_cyc[3];  // diagnostic builds: shader cycles of the tail iterations in refill / trace / shade
-    unsigned long long pass_stats[6];  // diagnostic builds, primary pass: passes, camera rays, cluster trips, paths that go on, shader cycles, shade cycles
+    unsigned long long pass_stats[10]; // diagnostic builds, primary pass: passes, camera rays, cluster trips, paths that go on, shader cycles, shade cycles,
+                                       // cycles handing out samples, cycles in the camera code, cycles moving records into slots, times that was done
     // -DRTIOW_DEBUG_TIMELINE builds: waves by the time (50 us bins from the first wave's start) their queue ran dry,
     // they first took the sparse trace, and they finished; iterations after running dry
     unsigned int tl_hist[3][64];
@@ -57,7 +58,7 @@ struct Counters {
 
 // Device-side shading record of one sphere (32 B), built by rtSetScene from RtSphere + RtMaterial.
 struct ShadeRec {
-    float albedo[3];
+    float albedo[3]; // lambertian, metal; dielectric: 1 / ior, (1 - 1/ior) / (1 + 1/ior), (1 - ior) / (1 + ior)
     float param;     // fuzz (metal) or index of refraction (dielectric)
     float inv_r;     // 1 / radius, rounded once on the host
     uint32_t kind;   // RT_MAT_*

@@ -109,6 +109,11 @@ HDI uint32_t tile_global_row(uint32_t lr, uint32_t row_block, uint32_t rank, uin
     if (count <= 1) return lr;
     return ((lr / row_block) * count + rank) * row_block + lr % row_block;
 }
+// (Round 4 tried the quotients by the frame's constants -- width, row_block -- as multiply-high and shift with host-made magic numbers:
+// two instructions instead of a dozen, four more kernel arguments -- and the cover frame 6.62 -> 6.76 ms: the clustered kernels have more
+// wave-uniform values than scalar registers, and four more of them cost more v_readlanes than the divisions cost instructions.)
+HDI uint32_t tile_global_row(const PathArgs& a, uint32_t lr) { return tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count); }
+HDI uint32_t pixel_row(const PathArgs& a, uint32_t pix) { return pix / a.width; }
 
 // ============================================================================
 // CH05 / CH06 — the reference's shaders
@@ -442,9 +447,12 @@ DI f3 random_unit_vector(Pcg& rng) {
 
 // one camera sample of pixel (i, j): SURVEY 9.4 / 9.5
 DI void camera_path(const PathArgs& a, uint32_t i, uint32_t j, uint32_t sample, Path& p) {
-    // (the camera's 22 floats stay kernel arguments in SGPRs, although the clustered kernel then spills 76 SGPRs into
-    // VGPR lanes: reading them from the kernel-argument segment here instead -- no spills at all -- took the cover
-    // frame from 9.6 to 10.25 ms)
+    // (The camera's 22 floats stay kernel arguments in SGPRs, although the clustered kernels then have half again as many wave-uniform
+    // values as scalar registers and keep the rest in VGPR lanes, a v_readlane away.  Round 2 read them from the kernel-argument segment
+    // here instead: scalar loads, 9.6 -> 10.25 ms.  Round 4 read them from a copy in LDS -- five broadcast reads per pass, 50 fewer
+    // spilled SGPRs: -0.3 ... -0.7 %, but the values are then per-lane registers in the kernel's tightest spot and 28 registers of other
+    // wave-uniform state go to scratch; dropped for the variant that spills nothing.  What did help the scalar side: every per-wave
+    // LDS area at a fixed offset from one base instead of seven bases -- 690 -> 490 v_readlanes in the code, no time either way.)
     const RtCamera& c = a.cam;
     p.rng = Pcg(a.seed, j * a.width + i, sample);
     const float u = (static_cast<float>(i) + p.rng.uniform()) * a.inv_wm1;
@@ -506,13 +514,17 @@ DI bool scatter(f3 ctr, const ShadeRec& m, float s, Path& p) {
         if (!(dot3(dir, n) > 0.0f)) return false;
         p.att = mk(p.att.x * m.albedo[0], p.att.y * m.albedo[1], p.att.z * m.albedo[2]);
     } else {
-        const float ratio = front ? (1.0f / m.param) : m.param;  // ior
+        // (a glass record's albedo words hold 1 / ior and Schlick's quotient for either side: rtSetScene)
+#ifndef RTIOW_GLASS_HOST
+#define RTIOW_GLASS_HOST 1  // (-DRTIOW_GLASS_HOST=0: A/B only -- the two quotients in the kernel)
+#endif
+        const float ratio = front ? (RTIOW_GLASS_HOST ? m.albedo[0] : 1.0f / m.param) : m.param;  // 1 / ior : ior
         const float nd = -dot3(p.du, n);
         const float cosv = (nd < 1.0f) ? nd : 1.0f;
         const float sinv = psqrt(fma_(-cosv, cosv, 1.0f));
         bool reflect = ratio * sinv > 1.0f;
         if (!reflect) {  // Schlick; (1-cos)^5 by repeated multiply, never powf
-            float r0 = (1.0f - ratio) / (1.0f + ratio);
+            float r0 = RTIOW_GLASS_HOST ? (front ? m.albedo[1] : m.albedo[2]) : (1.0f - ratio) / (1.0f + ratio);
             r0 = r0 * r0;
             const float x = 1.0f - cosv;
             const float x2 = x * x;
@@ -592,7 +604,7 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
     const uint32_t lr = (blockIdx.x / tiles_x) * 16u + (threadIdx.x >> 4);
     uint32_t n_paths = 0, n_segments = 0;
     if (i < a.width && lr < a.local_rows) {
-        const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
+        const uint32_t j = tile_global_row(a, lr);
         unsigned long long sr = 0ull, sg = 0ull, sb = 0ull;
         for (uint32_t s = 0; s < a.spp; ++s) {
             Path p;
@@ -736,8 +748,8 @@ constexpr uint32_t kAccWords = 4;                    // u64 words per entry: r, 
 constexpr uint32_t kWaveAccBytes = kAccEntries * kAccWords * 8u;  // 2 KiB of LDS per wave
 constexpr uint32_t kWavePixBytes = kAccEntries * 4u;              // ... and the pixel of each entry
 
-// Bookkeeping of a path in flight, ONE register: its pixel's accumulator entry, numbered across the workgroup (wave * kAccEntries +
-// index: 10 bits), the line buffer of its chunk + 1 (0: the pixel goes straight to the frame: 3 bits) and the segments it has taken
+// Bookkeeping of a path in flight, ONE register: its pixel's accumulator entry (one of its wave's kAccEntries; the field has 10 bits),
+// the line buffer of its chunk + 1 (0: the pixel goes straight to the frame: 3 bits) and the segments it has taken
 // (19 bits: rtRender caps max_depth accordingly).  The pixel itself is looked up by the entry when it completes (lds_pix: one word per
 // accumulator entry, written when the pixel is opened).  Rounds 1-3 carried pixel, entry, line and depth in a register each, eight
 // per lane -- the first place to look when the four-waves variant spilled 28.
@@ -763,6 +775,7 @@ struct PersistArgs {
     uint32_t chunk_until;  // ... which lasts while a queue has at least this many pixels left
     uint32_t fine_until;   // the first pixels of a queue's small-pool part that go out fine_pix at a time (0: none)
     uint32_t fine_pix;     // ... one iteration's worth of samples: 128 / spp pixels, at least one
+    uint32_t wave_bytes;   // LDS a wave has to itself behind the scene (accumulators, pixels, line buffers, lists, records)
     // the primary pass of the clustered kernels (see "The primary pass" below)
     uint32_t use_pass;     // != 0: camera rays take the primary pass (enough samples per pixel), 0: straight into the slots
     uint32_t pass_keep;    // camera paths a wave may keep in LDS beyond its idle slots (records of its own; 0: none)
@@ -2026,9 +2039,9 @@ struct ConeAxis {  // per lane: the cone of the span this half of the wave looks
 
 HDI ConeAxis cone_of_span(const PathArgs& a, const PersistArgs& g, uint32_t pix_lo, uint32_t pix_hi) {
     const RtCamera& c = a.cam;
-    const uint32_t lr = pix_lo / a.width;
+    const uint32_t lr = pixel_row(a, pix_lo);
     const uint32_t i_lo = pix_lo - lr * a.width, i_hi = i_lo + (pix_hi - pix_lo);
-    const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
+    const uint32_t j = tile_global_row(a, lr);
     const float uc = (0.5f * static_cast<float>(i_lo + i_hi) + 0.5f) * a.inv_wm1;
     const float vc = (static_cast<float>(j) + 0.5f) * a.inv_hm1;
     // half the span across, half a pixel up (g.h_len, g.v_len: |horizontal|, |vertical| with their margin)
@@ -2285,22 +2298,22 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     float4* lds_cbounds = reinterpret_cast<float4*>(lds_cidx + (ACCEL ? g.n_pad : 0u));
     // (boxes: centre + half extent, two float4 each; FLAT: without the flat axis, one float4 each)
     float4* lds_shade = lds_cbounds + (ACCEL ? (FLAT ? 1u : 2u) * (a.n_clusters + a.n_super) : 0u);
-    unsigned long long* lds_acc = reinterpret_cast<unsigned long long*>(lds_shade + (SHADE_LDS ? 2u * a.n : 0u));
+    // Behind the scene, one contiguous area per wave (g.wave_bytes of it): the accumulator entries of its pixels in flight {r, g, b,
+    // samples done | cost}, the pixel of each entry, the line buffers of the chunks it is assembling, (ACCEL) the result keys and the
+    // phase-2 work list(s) of trace_clustered, (ACCEL) pass_keep records of camera paths waiting for a slot -- all at fixed offsets
+    // from ONE base.  (Rounds 1-3 laid every one of these out as an array over the workgroup's waves: seven base addresses to hold.)
     const uint32_t waves_in_group = blockDim.x / 64u;
     const uint32_t wave_in_group = threadIdx.x / 64u;
-    // per accumulator entry: the pixel it belongs to (indexed like the entries, across the workgroup)
-    uint32_t* lds_pix = reinterpret_cast<uint32_t*>(lds_acc + waves_in_group * (kWaveAccBytes / 8u));
-    unsigned char* lds_per_wave = reinterpret_cast<unsigned char*>(lds_pix) + waves_in_group * kWavePixBytes;
-    // per wave: the line buffers of the chunks it is assembling
-    uint32_t* lds_line = reinterpret_cast<uint32_t*>(lds_per_wave) + wave_in_group * (kWaveLineBytes / 4u);
+    unsigned char* lds_wave = reinterpret_cast<unsigned char*>(lds_shade + (SHADE_LDS ? 2u * a.n : 0u)) + wave_in_group * g.wave_bytes;
+    unsigned long long* lds_acc = reinterpret_cast<unsigned long long*>(lds_wave);
+    uint32_t* lds_pix = reinterpret_cast<uint32_t*>(lds_wave + kWaveAccBytes);
+    uint32_t* lds_line = reinterpret_cast<uint32_t*>(lds_wave + kWaveAccBytes + kWavePixBytes);
     uint32_t* lds_line_meta = lds_line + kLineBufs * kChunkPix;  // per buffer {pixels done, pixels expected, cost (u64)}
-    // (ACCEL) per wave: the phase-2 work list and result keys of trace_clustered
-    [[maybe_unused]] unsigned long long* lds_results = reinterpret_cast<unsigned long long*>(
-        lds_per_wave + waves_in_group * kWaveLineBytes + wave_in_group * wave_item_bytes(a.n_super != 0u));
+    [[maybe_unused]] unsigned long long* lds_results = reinterpret_cast<unsigned long long*>(lds_wave + kWaveAccBytes + kWavePixBytes + kWaveLineBytes);
     [[maybe_unused]] uint16_t* lds_items = reinterpret_cast<uint16_t*>(lds_results + 128);
-    // (ACCEL) per wave: pass_keep records of camera paths waiting for a slot (three float4 each)
+    // (the small-scene variants never have super-clusters: their records sit at a fixed offset too)
     [[maybe_unused]] float4* lds_pbuf = reinterpret_cast<float4*>(
-        lds_per_wave + waves_in_group * (kWaveLineBytes + wave_item_bytes(a.n_super != 0u)) + wave_in_group * g.pass_keep * kPassRecBytes);
+        reinterpret_cast<unsigned char*>(lds_results) + wave_item_bytes(SHADE_LDS ? false : a.n_super != 0u));
     if (ACCEL) {
         for (uint32_t i = threadIdx.x; i < g.n_pad; i += blockDim.x) {
             lds_spheres[i] = a.cslots[i];
@@ -2359,7 +2372,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
 #endif
     [[maybe_unused]] uint32_t dbg_slow_trips = 0, dbg_cands = 0, dbg_iters = 0, dbg_sparse = 0;
     [[maybe_unused]] unsigned long long dbg_t_refill = 0, dbg_t_trace = 0, dbg_t_slow = 0, dbg_t_shade = 0;
-    [[maybe_unused]] unsigned long long dbg_pass[6] = {0, 0, 0, 0, 0, 0};
+    [[maybe_unused]] unsigned long long dbg_pass[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     [[maybe_unused]] const unsigned long long dbg_c0 = DBG_STAMP();
 #ifdef RTIOW_DEBUG_COUNTERS
     const unsigned long long dbg_w0 = wall_clock64();
@@ -2431,7 +2444,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 const uint32_t colour = close_pixel(a, done_pix, acc[0], acc[1], acc[2]);
                 const uint32_t line = meta_line(q.meta);
                 if (line == 0u) {
-                    const uint32_t lr = done_pix / a.width, i = done_pix - lr * a.width;
+                    const uint32_t lr = pixel_row(a, done_pix), i = done_pix - lr * a.width;
                     a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = colour;
                 } else {  // a pixel of a chunk this wave renders alone: into the line buffer
                     lds_line[(line - 1u) * kChunkPix + done_pix % kChunkPix] = colour;
@@ -2461,14 +2474,14 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             const int l = __builtin_ctzll(done_mask);
             done_mask &= done_mask - 1ull;
             const uint32_t m = __builtin_amdgcn_readlane(q.meta, l);
-            free_entries |= 1ull << (meta_entry(m) % kAccEntries);
+            free_entries |= 1ull << meta_entry(m);
             if (__builtin_amdgcn_readlane(static_cast<uint32_t>(line_full), l) != 0u) {
                 const uint32_t line = meta_line(m) - 1u;
                 const uint32_t first = __builtin_amdgcn_readlane(done_pix, l) / kChunkPix * kChunkPix;
                 const uint32_t count = g.total_pix - first < kChunkPix ? g.total_pix - first : kChunkPix;
                 if (lane < count) {
                     const uint32_t pix = first + lane;
-                    const uint32_t lr = pix / a.width, i = pix - lr * a.width;  // (a chunk may run over the end of a row)
+                    const uint32_t lr = pixel_row(a, pix), i = pix - lr * a.width;  // (a chunk may run over the end of a row)
                     a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = lds_line[line * kChunkPix + lane];
                 }
                 if (a.chunk_cost != nullptr && lane == 0u)  // this wave rendered the whole chunk: a plain store
@@ -2614,11 +2627,11 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     cur_pix = pix;
                     ++pool_next;
                     cur_s = 0u;
-                    if (lane < kAccWords) lds_acc[(wave_in_group * kAccEntries + cur_entry) * kAccWords + lane] = 0ull;
-                    if (lane == kAccWords) lds_pix[wave_in_group * kAccEntries + cur_entry] = pix;
+                    if (lane < kAccWords) lds_acc[cur_entry * kAccWords + lane] = 0ull;
+                    if (lane == kAccWords) lds_pix[cur_entry] = pix;
                 }
                 const uint32_t n = want - served < a.spp - cur_s ? want - served : a.spp - cur_s;
-                if (!on_range(served, n, cur_pix, wave_in_group * kAccEntries + cur_entry, cur_s)) break;  // (the pixel stays open)
+                if (!on_range(served, n, cur_pix, cur_entry, cur_s)) break;  // (the pixel stays open)
                 cur_s += n;
                 served += n;
             }
@@ -2657,6 +2670,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     for (uint32_t k = 0; k < kPassSpans; ++k) span_lo[k] = span_hi[k] = 0u;
                     uint32_t n_spans = 0u, last_pix = 0u, row_end = 0u;
                     const uint32_t want = n_idle + g.pass_keep < g.pass_cap ? n_idle + g.pass_keep : g.pass_cap;
+                    [[maybe_unused]] const unsigned long long th0 = DBG_STAMP();
                     const uint32_t granted = hand_out(want, [&](uint32_t first, uint32_t n, uint32_t pix, uint32_t entry, uint32_t s0) {
                         // (wave-uniform) the pixel continues the open span, or opens the next one -- a pass stops at the
                         // third: lanes 0-31 and 32-63 look at one span each when the cones are tested
@@ -2667,7 +2681,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                         } else {
                             if (n_spans == 0u) span_lo[0] = span_hi[0] = pix; else span_lo[1] = span_hi[1] = pix;
                             ++n_spans;
-                            row_end = (pix / a.width + 1u) * a.width;
+                            row_end = (pixel_row(a, pix) + 1u) * a.width;
                         }
                         last_pix = pix;
                         if (lane - first < n) {  // (unsigned: first <= lane < first + n)
@@ -2680,14 +2694,16 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     if (granted == 0u) break;  // queues dry, or all accumulator entries in use (then paths are in flight)
                     [[maybe_unused]] const unsigned long long tp0 = DBG_STAMP();
                     DBG_ADD(dbg_pass[0], lane == 0u ? 1u : 0u);
+                    DBG_ADD(dbg_pass[6], lane == 0u ? tp0 - th0 : 0ull);  // hand_out
                     DBG_ADD(dbg_pass[1], lane == 0u ? granted : 0u);
                     ps.active = lane < granted;
                     if (ps.active) {
-                        const uint32_t lr = gen_pix / a.width, i = gen_pix - lr * a.width;
-                        const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
+                        const uint32_t lr = pixel_row(a, gen_pix), i = gen_pix - lr * a.width;
+                        const uint32_t j = tile_global_row(a, lr);
                         camera_path(a, i, j, a.sample_offset + gen_s, ps.p);
                         ++n_paths;
                     }
+                    DBG_ADD(dbg_pass[7], lane == 0u ? DBG_STAMP() - tp0 : 0ull);  // camera_path
                     float pb;
                     int pb_i;
                     uint32_t pb_o;
@@ -2716,6 +2732,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 }
                 // the last `give` records go to the idle slots, numbered across both slots
                 // (a wave's LDS operations are performed in order: the records are there)
+                [[maybe_unused]] const unsigned long long td0 = DBG_STAMP();
                 const uint32_t give = pass_n < n_idle ? pass_n : n_idle;
                 uint32_t my_idx[kSlots];
                 my_idx[0] = lane_rank(idle0);
@@ -2735,6 +2752,8 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     }
                 }
                 pass_n -= give;
+                DBG_ADD(dbg_pass[8], lane == 0u ? DBG_STAMP() - td0 : 0ull);  // records -> slots
+                DBG_ADD(dbg_pass[9], lane == 0u ? 1u : 0u);
                 if (pass_n != 0u) break;  // (more records than idle slots: the slots are full)
             }
             if (SHADE_LDS && g.use_pass == 0u) {
@@ -2775,8 +2794,8 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     float4* rec = scratch4;  // [64] {o, d.x} then [64] {d.y, d.z, rng, -}
                     if (lane < granted) {
                         Path np;
-                        const uint32_t lr = gen_pix / a.width, i = gen_pix - lr * a.width;
-                        const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
+                        const uint32_t lr = pixel_row(a, gen_pix), i = gen_pix - lr * a.width;
+                        const uint32_t j = tile_global_row(a, lr);
                         camera_path(a, i, j, a.sample_offset + gen_s, np);
                         rec[lane] = make_float4(np.o.x, np.o.y, np.o.z, np.du.x);
                         rec[64u + lane] = make_float4(np.du.y, np.du.z, __uint_as_float(np.rng.state), 0.0f);
@@ -2818,8 +2837,8 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     return true;
                 });
                 if (got_sample) {  // start the sample
-                    const uint32_t lr = my_pix / a.width, i = my_pix - lr * a.width;
-                    const uint32_t j = tile_global_row(lr, a.row_block, a.tile_rank, a.tile_count);
+                    const uint32_t lr = pixel_row(a, my_pix), i = my_pix - lr * a.width;
+                    const uint32_t j = tile_global_row(a, lr);
                     camera_path(a, i, j, a.sample_offset + my_s, q.p);
                     q.active = true;
                     ++n_paths;
@@ -3043,7 +3062,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         atomicAdd(&a.counters->debug[4], dbg_t_trace);
         atomicAdd(&a.counters->debug[5], dbg_t_slow);
         atomicAdd(&a.counters->debug[6], dbg_t_shade);
-        for (int k = 0; k < 6; ++k) atomicAdd(&a.counters->pass_stats[k], dbg_pass[k]);
+        for (int k = 0; k < 10; ++k) atomicAdd(&a.counters->pass_stats[k], dbg_pass[k]);
         {
             const unsigned long long t0w = ~__hip_atomic_load(&a.counters->not_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long b = (wall_clock64() - t0w) / 12500ull;
@@ -3186,7 +3205,7 @@ __global__ __launch_bounds__(1024) void order_chunks_kernel(unsigned long long* 
 // ms against the default scheduler).  Round 3: iterative-minreg brings the flat-axis variant to 136 registers; held to 128
 // (-DRTIOW_SMALL_WAVES_PER_EU=4) it spilled 13 of them (28 by the end of the round) and runs FOUR waves per SIMD -- launch_path
 // then finds two groups of 512 threads per CU: cover frame 7.95 -> 7.19 ms, one eighth of it 1.33 -> 1.26 (interleaved A/B,
-// tools/ab_bench.py; iterative-minreg at three waves: 8.48).  Round 4: with Slot's bookkeeping in one register, 4 spilled.  The large-scene variants spill 115 registers at 128 and have no LDS for sixteen
+// tools/ab_bench.py; iterative-minreg at three waves: 8.48).  Round 4: with Slot's bookkeeping in one register and one base for the per-wave LDS areas, none.  The large-scene variants spill 115 registers at 128 and have no LDS for sixteen
 // waves' buffers, the flat-list kernels (95 registers) gain nothing: they stay with the default scheduler.
 #ifdef RTIOW_TU_SMALL_CLUSTERED
 PersistentKernelFn small_clustered_kernel(bool flat) {
@@ -3385,6 +3404,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
                 per_cu = blocks;
                 lds = need;
                 g.pass_keep = keep;
+                g.wave_bytes = wave_bytes(keep);
             }
         }
     }
