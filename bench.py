@@ -144,6 +144,58 @@ def cpu_baseline(V, sph, mat, cam, w, h, spp, depth, chunk, target_s=15.0):
     }
 
 
+def cold_and_moving_frames(V, torch, dev, device_id, sph, mat, cam, prm, w, h, timed_frame, warm_ctx, stream, scratch):
+    """Outside the timed region, N = 1: what the steady state of a static view leaves out.
+    first_frame_ms: a FRESH context's first frame of the same view -- scene just uploaded, no chunk order yet, counters set by a
+    memset -- checked against the timed frame.  moving_camera_ms_per_step: 16 frames of an orbit around the look-at point, a new
+    camera every frame, on the warm context (whose chunk order then belongs to the PREVIOUS view), by the wall clock around the
+    loop; the same loop with the camera standing still beside it; every orbit frame checked against a single-shot render of the
+    same view by a fresh context."""
+    import math
+    import time
+    res = {}
+    with V.Context(device_id) as fresh:
+        t0 = time.perf_counter()
+        fresh.set_scene(sph, mat)
+        res["scene_upload_ms"] = (time.perf_counter() - t0) * 1e3
+        ss = fresh.scene_stats()
+        res["scene_build_ms"] = ss.scene_build_ms
+        res["cluster_builds"] = int(ss.cluster_builds)
+        cold = torch.zeros((h, w), dtype=torch.int32, device=dev)
+        fresh.render_device(cam, prm, cold.data_ptr(), w * 4, stream.cuda_stream)
+        res["first_frame_ms"] = fresh.stats().kernel_ms
+        res["first_frame_vs_timed_frame"] = "identical" if bool(torch.equal(cold, timed_frame.to(dev))) else "DIFFERS"
+        fresh.render_device(cam, prm, cold.data_ptr(), w * 4, stream.cuda_stream)
+        res["second_frame_ms"] = fresh.stats().kernel_ms
+    n = 16
+    r0 = math.hypot(13.0, 3.0)
+    cams = [V.make_camera((r0 * math.cos(a), 2.0, r0 * math.sin(a)), (0, 0, 0), (0, 1, 0), 20.0, w / h, 0.1, 10.0)
+            for a in (math.atan2(3.0, 13.0) + 2.0 * math.pi * k / 96.0 for k in range(1, n + 1))]  # 3.75 degrees a frame
+    bufs = [torch.zeros((h, w), dtype=torch.int32, device=dev) for _ in range(n)]
+
+    def loop(cameras):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k, c in enumerate(cameras):
+            warm_ctx.render_device(c, prm, bufs[k].data_ptr(), w * 4, stream.cuda_stream)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / len(cameras) * 1e3
+
+    loop([cam] * 4)
+    res["static_camera_same_loop_ms_per_step"] = loop([cam] * n)
+    res["moving_camera_ms_per_step"] = loop(cams)
+    res["moving_camera"] = f"{n} frames of an orbit around the look-at point, 3.75 degrees a frame, a new RtCamera every frame"
+    bad = 0
+    with V.Context(device_id) as fresh:
+        fresh.set_scene(sph, mat)
+        for k, c in enumerate(cams):
+            fresh.render_device(c, prm, scratch.data_ptr(), w * 4, stream.cuda_stream)
+            torch.cuda.synchronize()
+            bad += 0 if bool(torch.equal(scratch, bufs[k])) else 1
+    res["moving_camera_frames_vs_single_shot"] = "identical" if bad == 0 else f"{bad} of {n} DIFFER"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -285,6 +337,7 @@ def run(args, np, torch, dist, V, D, world, rank, local_rank, backend, dev):
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
     st = ctx.stats()
+    ctx_clock_mhz = int(st.shader_clock_mhz)  # the shader clock the last timed frame's kernel measured for itself (RtStats)
 
     t = torch.tensor([elapsed, kernel_ms, float(st.segments)], dtype=torch.float64,
                      device=dev if backend == "nccl" else "cpu")
@@ -463,6 +516,13 @@ def run(args, np, torch, dist, V, D, world, rank, local_rank, backend, dev):
             out["config"]["other_kernel"] = {"kernel": KERNEL_NAMES[other], "kernel_ms": min(oms),
                                              "tests_per_segment": ost.sphere_tests / max(1, ost.segments),
                                              "roofline_frac": oflops / (min(oms) * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS}
+        if world == 1 and quick and scene == "cover":
+            out["config"].update(cold_and_moving_frames(V, torch, dev, local_rank, sph, mat, cam, prm, w, h, frame, ctx, streams[0],
+                                                        locals_[0]))
+        clock = ctx_clock_mhz
+        out["roofline"]["shader_clock_mhz"] = clock or None
+        out["roofline"]["peak_at_held_clock"] = FP32_VALU_PEAK_TFLOPS * clock / 2400.0 if clock else None
+        out["roofline"]["frac_at_held_clock"] = achieved / (FP32_VALU_PEAK_TFLOPS * clock / 2400.0) if clock else None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(V, sph, mat, cam, w, h, spp, depth, args.chunk_spp, args.cpu_seconds)
         print(json.dumps(out), flush=True)

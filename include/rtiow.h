@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RTIOW_ABI_VERSION 3
+#define RTIOW_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------ */
 enum {
@@ -149,6 +149,9 @@ typedef struct RtStats {
     uint32_t rows_rendered;
     uint32_t n_spheres;
     uint64_t debug[8];       /* kernel-internal counters of diagnostic builds (0 otherwise)   */
+    uint32_t shader_clock_mhz; /* PATH, persistent kernels: the shader clock the frame's kernel ran at, measured by one of
+                                  its waves (shader cycles per tick of the constant 100 MHz counter); 0 otherwise.  ABI 4. */
+    uint32_t reserved;
 } RtStats;
 
 typedef struct RtContext RtContext;
@@ -173,10 +176,16 @@ int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materi
  *      without a host sync; otherwise dst is host memory and the call returns
  *      when the frame is in it (fixing the unsynchronised compute->graphics
  *      hazard of main.cpp:324 vs :354).
- *      One exception to "enqueues and returns": a camera that has moved beyond 0.95 of the range the
- *      cluster boxes were inflated for (2 scene diagonals at rtSetScene), or back within an eighth of
- *      it, has the boxes rebuilt inside this call: the host waits for THIS context's previous frame (other
- *      contexts' frames on the device are not touched), then re-uploads.  Rare (a fly-away camera), never wrong. */
+ *      One exception to "enqueues and returns".  The cluster boxes are inflated for ray origins within a RANGE of the
+ *      scene's centre, in scene diagonals (diagonal = extent of the small spheres): rtSetScene chooses the scene's own range --
+ *      2 for a scene traced with one level of boxes, 0.6 for one traced with super-clusters (rtGetSceneStats reports it) -- and
+ *      builds the lists once.  A camera (with its lens) beyond 0.95 of the current range has the boxes rebuilt inside this call
+ *      for the first rung of {the scene's own range, 1, 2} that holds it with a tenth to spare, else for twice its distance; a
+ *      camera so far inside that one twice as far out would still fit a lower rung has them rebuilt for that rung.  The rebuild
+ *      happens before anything of the frame is enqueued: the host waits for THIS context's previous frame (other contexts'
+ *      frames on the device are not touched), builds (RtSceneStats.last_cluster_build_ms; not part of the frame's kernel_ms)
+ *      and re-uploads.  Beyond 64 diagonals the frame is rendered with the flat list.  Rare (a fly-away camera), never wrong.
+ *      max_depth above 524287 is refused (the kernels count a path's segments in 19 bits). */
 int rtRender(RtContext* ctx, const RtCamera* cam, const RtParams* params, void* dst,
              size_t dst_pitch, int dst_is_device, void* stream);
 
@@ -187,6 +196,19 @@ int rtRenderUbo(RtContext* ctx, const RtUbo5* ubo, uint32_t mode, void* dst, siz
 
 /* Waits for the context's outstanding work and fills stats of the last render. */
 int rtGetStats(RtContext* ctx, RtStats* out);
+
+/* What rtSetScene made of the scene (no device work; the reference uploads no scene, RTCHAP06/main.cpp:140-151). */
+typedef struct RtSceneStats {
+    double scene_build_ms;         /* host time of the last rtSetScene: shading records, cluster build, uploads       */
+    double last_cluster_build_ms;  /* ... of the last cluster build + upload alone (rtSetScene, or a re-box in rtRender) */
+    double range_diags;            /* range the boxes are inflated for now, in scene diagonals                          */
+    double base_range_diags;       /* the scene's own range, chosen by rtSetScene (2: one level of boxes, 0.6: two)      */
+    uint32_t cluster_builds;       /* times the lists of this scene were built and uploaded: 1 after rtSetScene, + 1 per re-box */
+    uint32_t n_clusters, n_super, n_large;
+    uint32_t flat_axis;            /* 0..2: the cluster boxes share an interval along this axis; 3: none                 */
+    uint32_t n_spheres;
+} RtSceneStats;
+int rtGetSceneStats(const RtContext* ctx, RtSceneStats* out);
 int rtSynchronize(RtContext* ctx);
 
 /* Which kernel variant the last RT_MODE_PATH render ran (RtParams.kernel 0 lets the library choose):
@@ -236,7 +258,7 @@ int rtMultiSelfTestHost(const uint32_t* full, uint32_t width, uint32_t height, u
 /* CPU check of the primary pass's cull (the kernels' own functions compiled for the host): for the span of pixels
  * pix_lo..pix_hi (indices row * width + column, one row) of a width x height image, which of the n_spheres spheres and
  * of the n_boxes boxes (six floats each: centre, half extent) can a camera ray of the span reach?  range_center /
- * range_rmax: the ray origins the scene's boxes are valid for (rtSetScene: two scene diagonals around its centre).
+ * range_rmax: the ray origins the scene's boxes are valid for (rtSetScene: the scene's range around its centre, see rtRender).
  * sphere_reach / box_reach receive one byte each (1 = may be reached).  Returns 1, 0 when the cull is off for this
  * camera (everything reached), or a negative RT_ERR_* code.  The test: no ray of the span, sampled as the camera
  * code samples it, hits a sphere or enters a box marked 0. */
@@ -255,6 +277,11 @@ int rtConeSelfTestHost(const RtCamera* cam, uint32_t width, uint32_t height, uin
 int rtClusterBuildHost(const RtSphere* spheres, uint32_t n_spheres, float range_diags, float* boxes, float* flat_boxes,
                        uint32_t box_cap, uint32_t* n_clusters, uint32_t* n_super, uint32_t* slot_index, uint32_t slot_cap,
                        uint32_t* n_slots, uint32_t* n_large_slots, uint32_t* flat_axis, float* flat_interval);
+/* CPU run of rtSetScene's own choice (no GPU involved): builds the lists exactly as rtSetScene does and reports how many
+ * builds that took (*builds_out: 1, or 2 for a scene whose super-cluster level does not fit the LDS of a CU), the range it
+ * chose (*range_out, scene diagonals) and the super-clusters of the result (*n_super_out). */
+int rtSceneClusterSelfTestHost(const RtSphere* spheres, uint32_t n_spheres, uint32_t* builds_out, double* range_out,
+                               uint32_t* n_super_out);
 
 /* CPU check of the chunk-order layout (cost-ordered dequeue): for a tile of n_chunks 32-pixel chunks, the words
  * rtRender allocates for the order (*words_out) and the highest word the kernels index (*max_slot_out), computed with

@@ -31,3 +31,12 @@ def gpu_ctx(rt):
     ctx = rt.Context(0)  # raises (does not skip) when the HIP path is unusable
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(scope="session")
+def knobs_ctx(rt):
+    """A context on librtiow_hip_knobs.so: the shipped kernels + the RTIOW_DEBUG_* knobs, which the shipped library does not
+    read (csrc/rtiow_device.h: debug_knob).  For the parity tests that force a kernel variant through the environment."""
+    ctx = rt.Context(0, lib_path=rt.api.KNOBS_LIB_PATH)
+    yield ctx
+    ctx.close()

@@ -92,10 +92,10 @@ def test_ch_row_kernel_equals_the_tiled_form_and_the_oracle(gpu_ctx, oracle, mod
 
 
 @pytest.mark.parametrize("mode", [V.RT_MODE_CH05, V.RT_MODE_CH06])
-def test_ch_lean_roots_and_quotients_equal_the_full_forms_and_the_oracle(gpu_ctx, oracle, mode, monkeypatch):
+def test_ch_lean_roots_and_quotients_equal_the_full_forms_and_the_oracle(gpu_ctx, knobs_ctx, oracle, mode, monkeypatch):
     """ch_kernel_rows takes its square roots and quotients without hipcc's range handling (ch_sqrt, ch_div: the cores of
     the correctly rounded expansions) when the camera's proportions are moderate, and with the full forms otherwise
-    (RTIOW_DEBUG_CH_FULL forces those): random UBOs -- viewports and focal lengths over six orders of magnitude, the
+    (RTIOW_DEBUG_CH_FULL forces those -- in the knobs build of the library: the shipped one reads no environment): random UBOs -- viewports and focal lengths over six orders of magnitude, the
     sphere anywhere from a dot to larger than the frame -- must give the oracle's bytes either way; so must UBOs outside the
     lean range (tiny, huge and negative viewports)."""
     rng = np.random.default_rng(mode)
@@ -120,10 +120,11 @@ def test_ch_lean_roots_and_quotients_equal_the_full_forms_and_the_oracle(gpu_ctx
         ubos.append(u)
     for u in ubos:
         want = oracle.render_ubo(u, mode)
-        monkeypatch.delenv("RTIOW_DEBUG_CH_FULL", raising=False)
-        lean = gpu_ctx.render_ubo(u, mode)
         monkeypatch.setenv("RTIOW_DEBUG_CH_FULL", "1")
-        full = gpu_ctx.render_ubo(u, mode)
+        lean = gpu_ctx.render_ubo(u, mode)    # (the shipped library: the variable means nothing to it)
+        full = knobs_ctx.render_ubo(u, mode)  # (the knobs build: hipcc's full forms)
+        monkeypatch.delenv("RTIOW_DEBUG_CH_FULL", raising=False)
+        assert np.array_equal(knobs_ctx.render_ubo(u, mode), lean)  # (same kernels without the knob)
         what = (u.imageWidth, u.imageHeight, u.viewportWidth, u.viewportHeight, u.focalLength)
         assert np.array_equal(full, want), (what, _diff(full, want))
         assert np.array_equal(lean, want), (what, _diff(lean, want))
@@ -539,3 +540,38 @@ def test_error_behaviour(gpu_ctx, oracle):
         V.Context(99)
     assert e.value.code == V.RT_ERR_NO_DEVICE
     fresh.close()
+
+
+@pytest.mark.gpu
+def test_a_camera_that_moves_every_frame(oracle):
+    """The frame loop of RTCHAP06/main.cpp:304-360 with a camera that changes every frame: one context, the
+    chunk order of frame k made from the costs of frame k - 1 -- another view --, twelve frames of an orbit, then a camera that flies
+    away by a factor 1.7 per frame (up the ladder of ranges the cluster boxes are rebuilt for, and past 64 scene diagonals onto the
+    flat list) and comes back.  Every frame is the oracle's frame of that view, byte for byte; the re-boxes happen before the frame's
+    events are recorded (kernel_ms stays a kernel's time) and are counted in RtSceneStats."""
+    import math
+    w, h = 160, 100
+    sph, mat = V.make_cover_scene(1, 11)
+    base = dict(spp=8, max_depth=50, seed=3)
+    r0 = math.hypot(13.0, 3.0)
+    views = [((r0 * math.cos(0.23 + 0.21 * k), 2.0 + 0.1 * k, r0 * math.sin(0.23 + 0.21 * k)), 20.0) for k in range(12)]
+    views += [((13.0 * 1.7 ** k, 2.0 * 1.7 ** k, 3.0 * 1.7 ** k), 20.0 / 1.5 ** k) for k in range(1, 12)]  # out to ~4500 units
+    views += [((13.0 * 1.7 ** k, 2.0 * 1.7 ** k, 3.0 * 1.7 ** k), 20.0 / 1.5 ** k) for k in (8, 5, 2, 0)]   # ... and back
+    with V.Context(0) as ctx:
+        ctx.set_scene(sph, mat)
+        assert ctx.scene_stats().cluster_builds == 1
+        kernels, builds = [], []
+        for frm, fov in views:
+            cam = V.make_camera(frm, (0, 0, 0), (0, 1, 0), fov, w / h, 0.05, math.dist(frm, (0, 0, 0)))
+            prm = V.make_params(w, h, **base)
+            got = ctx.render(cam, prm)
+            st = ctx.stats()
+            want, segs = oracle.render(sph, mat, cam, prm)
+            assert np.array_equal(got, want) and st.segments == segs, (frm, _diff(got, want))
+            assert st.kernel_ms < 50.0  # (a kernel's time: the host-side re-box is not inside the events)
+            kernels.append(ctx.last_kernel())
+            builds.append(ctx.scene_stats().cluster_builds)
+        assert builds[11] == 1                      # the orbit never leaves the scene's own range
+        assert builds[-1] > builds[11] + 2          # ... the fly-away climbs the ladder and comes down again
+        assert V.KERNEL_PERSISTENT in kernels and kernels[-1] == V.KERNEL_CLUSTERED  # flat list beyond 64 diagonals, then back
+        assert abs(ctx.scene_stats().range_diags - 2.0) < 1e-9  # back on the scene's own rung

@@ -261,7 +261,7 @@ def test_flat_axis_box_test_equals_whole_boxes(oracle, monkeypatch, up_axis):
         tests = {}
         for mode in ("0", "1", "2"):  # whole boxes; flat forced; the library's own choice
             monkeypatch.setenv("RTIOW_DEBUG_FLAT", mode)
-            with V.Context(0) as ctx:
+            with V.Context(0, lib_path=V.api.KNOBS_LIB_PATH) as ctx:  # (the knobs build: the shipped library reads no environment)
                 ctx.set_scene(sph, mat)
                 for kernel in (V.KERNEL_CLUSTERED, V.KERNEL_CLUSTERED_PASS):
                     got = ctx.render(cam, V.make_params(w, h, kernel=kernel, **base))

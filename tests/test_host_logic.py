@@ -3,6 +3,7 @@ against the oracle's independent restatement.  No compute entry point is called.
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -19,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     lib = V.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.rtAbiVersion() == 3
+    assert lib.rtAbiVersion() == 4
 
 
 def test_chunk_order_fits_its_allocation():
@@ -118,7 +119,7 @@ def test_header_is_plain_c_and_links(tmp_path):
                    '};\n    RtParams p; RtStats s; (void)p; (void)s;\n'
                    '    return (sizeof(fns) / sizeof(fns[0]) == %d && sizeof(RtUbo5) == 20 && sizeof(RtSphere) == 16 &&\n'
                    '            sizeof(RtMaterial) == 32 && sizeof(RtCamera) == 88 && sizeof(RtParams) == 56 &&\n'
-                   '            rtAbiVersion() == 3 && rtTileRowCount(10, 4, 0, 2) == 6) ? 0 : 1;\n}\n' % len(names))
+                   '            rtAbiVersion() == 4 && rtTileRowCount(10, 4, 0, 2) == 6) ? 0 : 1;\n}\n' % len(names))
     libdir = os.path.join(ROOT, "vulkan-rtiow_amd")
     exe = tmp_path / "abi"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-Wno-pedantic",
@@ -415,3 +416,39 @@ def test_primary_pass_cone_cull_is_conservative(case):
     assert not (enters & ~breach).any(), (case, np.nonzero(enters & ~breach)[0][:5])
     if cull and hi - lo <= 7 and aperture < 0.5 * scale:
         assert sreach.mean() < 0.6 and breach.mean() < 0.7, (case, sreach.mean(), breach.mean())  # it does cull
+
+
+def test_a_scene_is_boxed_once_by_rtsetscene():
+    """rtSetScene decides a scene's range -- 0.6 scene diagonals with super-clusters, 2 without -- BEFORE it makes a box and
+    builds the lists once (round 3 built every scene with super-clusters twice: the one-level range first).  The CPU run of
+    its own choice (rtSceneClusterSelfTestHost -> rtiow::build_scene_clusters, the function rtSetScene calls) counts the calls
+    of build_clusters."""
+    import vulkan_rtiow_amd as V
+    for grid, want_range, supers in ((11, 2.0, False), (16, 0.6, True), (32, 0.6, True)):
+        sph, _ = V.make_cover_scene(1, grid)
+        got = V.scene_cluster_selftest_host(sph)
+        assert got["builds"] == 1, (grid, got)
+        assert abs(got["range_diags"] - want_range) < 1e-12 and (got["n_super"] != 0) == supers, (grid, len(sph), got)
+
+
+def test_the_shipped_library_reads_no_debug_environment():
+    """The RTIOW_DEBUG_* tuning / test knobs are compiled into the knobs and diagnostic builds only (rtiow_device.h:
+    debug_knob): the shipped library holds none of their names -- no environment variable can change its kernel choice, and
+    its render path makes no getenv calls -- while the knobs build, which two GPU parity tests and the A/B tools load, holds them."""
+    lib = os.path.join(ROOT, "vulkan-rtiow_amd", "librtiow_hip.so")
+    knobs = os.path.join(ROOT, "vulkan-rtiow_amd", "librtiow_hip_knobs.so")
+    if not (os.path.exists(lib) and os.path.exists(knobs)):
+        pytest.skip("libraries not built")
+    assert b"RTIOW_DEBUG_" not in open(lib, "rb").read()
+    assert b"RTIOW_DEBUG_FLAT" in open(knobs, "rb").read()
+
+
+def test_fail_loudly_lets_a_clean_exit_through():
+    """dist.fail_loudly turns any failure inside it into an immediate os._exit(13) -- but sys.exit(0) is not a failure."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import vulkan_rtiow_amd as V; from importlib import import_module; "
+            "d = import_module('vulkan-rtiow_amd.dist')\n"
+            "with d.fail_loudly('x'):\n    sys.exit(int(sys.argv[1]))\n") % ROOT
+    for want in (0, 3):
+        res = subprocess.run([sys.executable, "-c", code, str(want)], capture_output=True, text=True, timeout=300)
+        assert res.returncode == want, (want, res.returncode, res.stderr[-500:])

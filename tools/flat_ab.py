@@ -2,6 +2,7 @@
 tile, 1 spp, C5 at 16 spp.  Frames must be identical.  usage: flat_ab.py [rounds]"""
 import os, sys, statistics, zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("RTIOW_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vulkan-rtiow_amd", "librtiow_hip_knobs.so"))  # the RTIOW_DEBUG_* knobs exist in this build only
 import vulkan_rtiow_amd as V
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 cases = [("cover 1200x800x100", 11, 1200, 800, 100, 1), ("cover tile 0 of 8", 11, 1200, 800, 100, 8), ("cover 1200x800x1", 11, 1200, 800, 1, 1),

@@ -2,6 +2,7 @@
 must have before it runs a pass (RTIOW_DEBUG_PASS_MIN_IDLE), cover scenes of 2000-4100 spheres.  usage: keep_ab.py [spp]"""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("RTIOW_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vulkan-rtiow_amd", "librtiow_hip_knobs.so"))  # the RTIOW_DEBUG_* knobs exist in this build only
 import vulkan_rtiow_amd as V
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 w, h = 1200, 800

@@ -2,6 +2,7 @@
 usage: min_idle_ab.py [grid_half] [spp]"""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("RTIOW_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vulkan-rtiow_amd", "librtiow_hip_knobs.so"))  # the RTIOW_DEBUG_* knobs exist in this build only
 import vulkan_rtiow_amd as V
 grid = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 256

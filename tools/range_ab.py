@@ -2,6 +2,7 @@
 beyond it tests enlarged boxes instead of taking every cluster.  usage: range_ab.py"""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("RTIOW_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vulkan-rtiow_amd", "librtiow_hip_knobs.so"))  # the RTIOW_DEBUG_* knobs exist in this build only
 import vulkan_rtiow_amd as V
 w, h = 1200, 800
 for grid, spp, tile in ((32, 64, 1), (20, 64, 1), (14, 64, 1)):

@@ -18,6 +18,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RTIOW_LIB lets a diagnostic build of the same ABI (e.g. -DRTIOW_DEBUG_COUNTERS) stand in
 LIB_PATH = os.environ.get("RTIOW_LIB") or os.path.join(_HERE, "librtiow_hip.so")
+# The shipped kernels + the RTIOW_DEBUG_* tuning / test knobs, which the shipped library does not read (csrc/rtiow_device.h:
+# debug_knob; `make -C csrc knobs`): Context(lib_path=KNOBS_LIB_PATH) for the tools and tests that force a kernel variant.
+KNOBS_LIB_PATH = os.path.join(_HERE, "librtiow_hip_knobs.so")
 
 # ---- enums (include/rtiow.h) -------------------------------------------------
 RT_OK = 0
@@ -55,10 +58,17 @@ class RtParams(C.Structure):
                  "row_block", "tile_rank", "tile_count", "kernel", "sample_offset", "accumulate")]
 
 
+class RtSceneStats(C.Structure):
+    _fields_ = [("scene_build_ms", C.c_double), ("last_cluster_build_ms", C.c_double), ("range_diags", C.c_double),
+                ("base_range_diags", C.c_double), ("cluster_builds", C.c_uint32), ("n_clusters", C.c_uint32),
+                ("n_super", C.c_uint32), ("n_large", C.c_uint32), ("flat_axis", C.c_uint32), ("n_spheres", C.c_uint32)]
+
+
 class RtStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("paths", C.c_uint64), ("segments", C.c_uint64),
                 ("sphere_tests", C.c_uint64), ("bytes_written", C.c_uint64),
-                ("rows_rendered", C.c_uint32), ("n_spheres", C.c_uint32), ("debug", C.c_uint64 * 8)]
+                ("rows_rendered", C.c_uint32), ("n_spheres", C.c_uint32), ("debug", C.c_uint64 * 8),
+                ("shader_clock_mhz", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 SPHERE_DTYPE = np.dtype([("cx", "<f4"), ("cy", "<f4"), ("cz", "<f4"), ("radius", "<f4")])
@@ -103,6 +113,8 @@ SIGNATURES = {
     "rtMultiSelfTestHost": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _VP]),
     "rtChunkOrderSelfTestHost": (C.c_int, [C.c_uint32, _VP, _VP]),
     "rtClusterBuildHost": (C.c_int, [_VP, C.c_uint32, C.c_float, _VP, _VP, C.c_uint32, _VP, _VP, _VP, C.c_uint32, _VP, _VP, _VP, _VP]),
+    "rtSceneClusterSelfTestHost": (C.c_int, [_VP, C.c_uint32, _VP, _VP, _VP]),
+    "rtGetSceneStats": (C.c_int, [_VP, _VP]),
     "rtConeSelfTestHost": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _VP, C.c_float, _VP, C.c_uint32,
                                      _VP, C.c_uint32, _VP, _VP]),
 }
@@ -151,7 +163,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.rtAbiVersion() != 3:
+    if lib.rtAbiVersion() != 4:
         raise ImportError("librtiow_hip.so has an unexpected ABI version")
     if path == LIB_PATH:
         _lib = lib
@@ -239,8 +251,8 @@ def make_params(width, height, spp=1, max_depth=50, seed=1, mode=RT_MODE_PATH,
 class Context:
     """One GPU's render context (rtCreate .. rtDestroy)."""
 
-    def __init__(self, device_id: int = 0):
-        self._lib = load_library()
+    def __init__(self, device_id: int = 0, lib_path: Optional[str] = None):
+        self._lib = load_library(lib_path) if lib_path else load_library()
         self._h = _VP()
         code = self._lib.rtCreate(device_id, C.byref(self._h))
         if code != RT_OK:
@@ -308,6 +320,11 @@ class Context:
     def stats(self) -> RtStats:
         st = RtStats()
         _check(self._h, self._lib.rtGetStats(self._h, C.byref(st)), "rtGetStats")
+        return st
+
+    def scene_stats(self) -> RtSceneStats:
+        st = RtSceneStats()
+        _check(self._h, self._lib.rtGetSceneStats(self._h, C.byref(st)), "rtGetSceneStats")
         return st
 
     def last_kernel(self) -> int:
@@ -425,6 +442,18 @@ def cluster_build_host(spheres: np.ndarray, range_diags: float = 2.0) -> dict:
     return {"n_clusters": nc.value, "n_super": ns.value, "boxes": boxes[:n].copy(), "flat_boxes": flat[:n].copy(),
             "slot_index": slots[:nslots.value].copy(), "n_large_slots": nlarge.value, "flat_axis": axis.value,
             "flat_interval": (float(interval[0]), float(interval[1]))}
+
+
+def scene_cluster_selftest_host(spheres: np.ndarray) -> dict:
+    """rtSceneClusterSelfTestHost: rtSetScene's own choice of range and levels, run on the CPU -- how many cluster builds it
+    took, the range (scene diagonals) and the super-clusters of the lists it would upload."""
+    lib = load_library()
+    spheres = np.ascontiguousarray(spheres)
+    builds, n_super, rng = C.c_uint32(0), C.c_uint32(0), C.c_double(0.0)
+    code = lib.rtSceneClusterSelfTestHost(spheres.ctypes.data, len(spheres), C.byref(builds), C.byref(rng), C.byref(n_super))
+    if code != RT_OK:
+        raise RtError(code, "rtSceneClusterSelfTestHost")
+    return {"builds": builds.value, "range_diags": rng.value, "n_super": n_super.value}
 
 
 def chunk_order_selftest_host(n_chunks: int) -> Tuple[int, int]:

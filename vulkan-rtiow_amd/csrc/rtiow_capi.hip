@@ -13,6 +13,7 @@
 #include <vector>
 #include <cmath>
 #include <algorithm>
+#include <chrono>
 
 #include "../../include/rtiow.h"
 #include "rtiow_device.h"
@@ -125,20 +126,25 @@ int rtDestroy(RtContext* ctx) {
 }
 
 // The range the boxes are built for when the camera (with its lens) is `need` scene diagonals from the scene's centre: the
-// scene's own (kRangeOneLevel / kRangeTwoLevel), else the first of 1 and 2 diagonals that holds the camera with a tenth to spare,
+// scene's own (`base`: kRangeOneLevel, or kRangeTwoLevel for a scene that is traced with its super-cluster level), else the first of 1 and 2 diagonals that holds the camera with a tenth to spare,
 // else twice its distance.
-static double range_for_camera(double need, bool two_level) {
-    const double base = two_level ? rtiow::kRangeTwoLevel : rtiow::kRangeOneLevel;
+static double range_for_camera(double need, double base) {
     for (double r : {base, 1.0, 2.0})
         if (r >= base && need <= 0.9 * r) return r;
     return 2.0 * need;
 }
 
-// Builds the two-level list of the clustered kernel for ray origins up to range_diags scene diagonals
-// from the scene's centre and uploads it (the context's stream must be idle).
+// Builds the two-level list of the clustered kernel -- for ray origins up to range_diags scene diagonals from the scene's centre, or
+// (range_diags <= 0: rtSetScene) for the scene's own range, ONE build (rtiow::build_scene_clusters) -- and uploads it (the context's
+// stream must be idle).  On failure the context holds no clustered list at all (rtRender then falls back to nothing stale).
 static int upload_clusters(RtContext* ctx, double range_diags) {
+    const auto t0 = std::chrono::steady_clock::now();
     rtiow::ClusterScene cs;
-    rtiow::build_clusters(ctx->host_spheres.data(), static_cast<uint32_t>(ctx->host_spheres.size()), range_diags, cs);
+    const uint32_t n = static_cast<uint32_t>(ctx->host_spheres.size());
+    if (range_diags > 0.0) rtiow::build_clusters(ctx->host_spheres.data(), n, range_diags, cs);
+    else rtiow::build_scene_clusters(ctx->host_spheres.data(), n, cs);
+    ctx->n_clusters = ctx->n_super = ctx->n_large = ctx->n_large_slots = ctx->n_cslots = 0u;  // (until the new lists are in place)
+    ++ctx->cluster_uploads;
     // (Re-)allocate only when the lists have grown -- re-boxing the same spheres for another range never does: hipFree
     // synchronises the whole device, and other contexts may have frames in flight on it.  The copies go through the
     // context's own stream (the caller has made sure no frame of this context still reads the old lists).
@@ -173,7 +179,8 @@ static int upload_clusters(RtContext* ctx, double range_diags) {
     ctx->cluster_rmax2 = cs.rmax2;
     ctx->cluster_far_k = cs.far_k;
     ctx->cluster_far_c = cs.far_c;
-    ctx->cluster_range = range_diags < rtiow::kRangeFloor ? rtiow::kRangeFloor : range_diags;
+    ctx->cluster_range = cs.range_diags;
+    ctx->last_cluster_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RT_OK;
 }
 
@@ -191,6 +198,7 @@ int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materi
         if (!(spheres[i].radius != 0.0f))
             return fail(ctx, RT_ERR_INVALID, "rtSetScene: zero or NaN radius");
     }
+    const auto t_scene = std::chrono::steady_clock::now();
     RT_HIP(ctx, hipSetDevice(ctx->device));
     // (no frame of this context may still read the old scene: its last render may have gone to a caller's stream)
     if (ctx->have_done) RT_HIP(ctx, hipEventSynchronize(ctx->ev_done));
@@ -234,10 +242,43 @@ int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materi
     if (e != hipSuccess) return fail_hip(ctx, e, "hipMemcpy(shading records)");
     RT_HIP(ctx, hipMemcpy(ctx->d_spheres, spheres, sizeof(float4) * n_spheres, hipMemcpyHostToDevice));
     ctx->host_spheres.assign(spheres, spheres + n_spheres);
-    int rc = upload_clusters(ctx, rtiow::kRangeOneLevel);
-    if (rc == RT_OK && ctx->n_super != 0u) rc = upload_clusters(ctx, rtiow::kRangeTwoLevel);  // (see kRangeTwoLevel)
+    ctx->cluster_uploads = 0;
+    int rc = upload_clusters(ctx, 0.0);  // the scene's own range (kRangeOneLevel / kRangeTwoLevel), decided before a box is made
     if (rc != RT_OK) return rc;
+    ctx->scene_base_range = ctx->cluster_range;
     ctx->n_spheres = n_spheres;
+    ctx->scene_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_scene).count();
+    return RT_OK;
+}
+
+// The cluster boxes are inflated for ray origins within cluster_range scene diagonals of the scene's centre
+// (rtiow_clusters.cpp); the kernel sends any ray that starts farther out through every cluster (enlarged by its own margin
+// where that is cheap).  A camera out there would lose the culls of its primary rays: the boxes are rebuilt for the next rung
+// that holds it (range_for_camera: wider margins; rare, so this context's frames are simply drained first), and again once
+// the camera is back well inside a lower rung.  Beyond 64 diagonals the margins swallow the boxes: flat list.
+// Called at the top of rtRender, before anything of the frame is enqueued or recorded: the rebuild is host work (it is
+// in RtSceneStats.last_cluster_build_ms, not in the frame's kernel_ms), and a failure leaves the frame sequence untouched.
+static int boxes_for_camera(RtContext* ctx, const RtCamera* cam, uint32_t* kernel) {
+    if (*kernel != rtiow::KERNEL_CLUSTERED && *kernel != rtiow::KERNEL_CLUSTERED_PASS && *kernel != rtiow::KERNEL_DEFAULT) return RT_OK;
+    double d2 = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        const double d = double(cam->origin[k]) - double(ctx->cluster_center[k]);
+        d2 += d * d;
+    }
+    const double need = (std::sqrt(d2) + double(cam->lens_radius)) / std::max(1e-30, double(ctx->cluster_diag));
+    if (!(need <= 64.0)) {
+        *kernel = rtiow::KERNEL_PERSISTENT;
+        return RT_OK;
+    }
+    const double base = ctx->scene_base_range;  // (the range rtSetScene chose: build_scene_clusters)
+    if (need > 0.95 * ctx->cluster_range || range_for_camera(2.0 * need, base) < ctx->cluster_range) {
+        // (out of the range, or so far inside that a camera twice as far out would still fit the rung below)
+        // (the old lists are read by this context's frames only: wait for the last of them -- ev_done marks the end
+        // of everything the previous render enqueued -- not for the device, where other contexts' frames are in flight)
+        if (ctx->have_done) RT_HIP(ctx, hipEventSynchronize(ctx->ev_done));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return upload_clusters(ctx, range_for_camera(need, base));
+    }
     return RT_OK;
 }
 
@@ -259,6 +300,11 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
 
     RT_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_handle ? static_cast<hipStream_t>(stream_handle) : ctx->stream;
+    uint32_t kernel = prm->kernel;
+    if (!is_ch) {
+        int rc = boxes_for_camera(ctx, cam, &kernel);
+        if (rc != RT_OK) return rc;
+    }
 
     uint32_t* out = static_cast<uint32_t*>(dst);
     uint32_t out_stride = static_cast<uint32_t>(dst_pitch / 4);
@@ -359,54 +405,12 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
         a.dst_stride = out_stride;
         a.counters = counters;
         a.next_counters = ctx->d_counters + (ctx->counter_index ^ 1u);
-        // The cluster boxes are inflated for ray origins within cluster_range scene diagonals of the
-        // scene's centre (rtiow_clusters.cpp); the kernel sends any ray that starts farther out through
-        // every cluster (enlarged by its own margin where that is cheap).  A camera out there would lose the culls of its
-        // primary rays: the boxes are rebuilt for the next rung that holds it (range_for_camera: wider margins; rare, so the
-        // streams are simply drained first), and again once the camera is back well inside a lower rung.  Beyond 64
-        // diagonals the margins swallow the boxes: flat list.
-        uint32_t kernel = prm->kernel;
-        if (kernel == rtiow::KERNEL_CLUSTERED || kernel == rtiow::KERNEL_CLUSTERED_PASS || kernel == rtiow::KERNEL_DEFAULT) {
-            double d2 = 0.0;
-            for (int k = 0; k < 3; ++k) {
-                const double d = double(cam->origin[k]) - double(ctx->cluster_center[k]);
-                d2 += d * d;
-            }
-            const double need = (std::sqrt(d2) + double(cam->lens_radius)) / std::max(1e-30, double(ctx->cluster_diag));
-            if (!(need <= 64.0)) {
-                kernel = rtiow::KERNEL_PERSISTENT;
-            } else if (need > 0.95 * ctx->cluster_range || range_for_camera(2.0 * need, ctx->n_super != 0u) < ctx->cluster_range) {
-                // (out of the range, or so far inside that a camera twice as far out would still fit the rung below)
-                // (the old lists are read by this context's frames only: wait for the last of them -- ev_done marks the end
-                // of everything the previous render enqueued -- not for the device, where other contexts' frames are in flight)
-                if (ctx->have_done) RT_HIP(ctx, hipEventSynchronize(ctx->ev_done));
-                RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                int rc = upload_clusters(ctx, range_for_camera(need, ctx->n_super != 0u));
-                if (rc != RT_OK) return rc;
-                a.cslots = ctx->d_cslots;
-                a.cidx = ctx->d_cidx;
-                a.cbounds = ctx->d_cbounds;
-                a.n_clusters = ctx->n_clusters;
-                a.n_super = ctx->n_super;
-                a.n_large = ctx->n_large;
-                a.n_large_slots = ctx->n_large_slots;
-                a.n_cslots = ctx->n_cslots;
-                a.flat_axis = ctx->flat_axis;
-        a.cbounds2 = ctx->d_cbounds + 2u * size_t(ctx->n_clusters + ctx->n_super);
-                a.flat_mid = ctx->flat_mid;
-                a.flat_half = ctx->flat_half;
-                for (int k = 0; k < 3; ++k) a.ccenter[k] = ctx->cluster_center[k];
-                a.crmax2 = ctx->cluster_rmax2;
-                a.cfar_k = ctx->cluster_far_k;
-                a.cfar_c = ctx->cluster_far_c;
-            }
-        }
         // cost-ordered dequeue (persistent kernels): this frame is dealt in the order the last frame of the
         // same shape suggests, and leaves its own per-chunk costs for the next one
 #ifdef RTIOW_NO_ORDER  // (tuning only)
         const bool ordered = false;
 #else
-        const bool ordered = kernel != rtiow::KERNEL_PIXEL && !getenv("RTIOW_DEBUG_NO_ORDER");  // (tuning only)
+        const bool ordered = kernel != rtiow::KERNEL_PIXEL && !rtiow::debug_knob("RTIOW_DEBUG_NO_ORDER");  // (tuning only)
 #endif
         bool collect = false;
         if (ordered) {
@@ -543,8 +547,9 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
         ctx->stats.sphere_tests = ctx->h_counters->tests ? ctx->h_counters->tests
                                                          : ctx->stats.segments * ctx->stats.n_spheres;
         for (int k = 0; k < 8; ++k) ctx->stats.debug[k] = ctx->h_counters->debug[k];
+        ctx->stats.shader_clock_mhz = ctx->h_counters->clk_ticks ? static_cast<uint32_t>(ctx->h_counters->clk_cycles * 100ull / ctx->h_counters->clk_ticks) : 0u;
 #ifdef RTIOW_DEBUG_TIMELINE
-        if (const char* path = getenv("RTIOW_DEBUG_WAVELOG")) {  // one line per wave: see Counters::tl_wave
+        if (const char* path = rtiow::debug_knob("RTIOW_DEBUG_WAVELOG")) {  // one line per wave: see Counters::tl_wave
             if (FILE* f = fopen(path, "w")) {
                 for (int wv = 0; wv < 8192; ++wv) {
                     const unsigned int* r = ctx->h_counters->tl_wave[wv];
@@ -561,7 +566,7 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
                             b[1] * 0.01 / b[0], double(b[2]) / b[0], double(b[3]) / b[0]);
             }
         }
-        if (getenv("RTIOW_DEBUG_HIST")) {
+        if (rtiow::debug_knob("RTIOW_DEBUG_HIST")) {
             const rtiow::Counters& c = *ctx->h_counters;
             static const char* names[3] = {"dry   ", "sparse", "done  "};
             for (int k = 0; k < 3; ++k) {
@@ -582,7 +587,7 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
         }
 #endif
 #ifdef RTIOW_DEBUG_COUNTERS
-        if (getenv("RTIOW_DEBUG_HIST")) {  // diagnostic builds: when waves ran dry / finished, 0.125 ms bins
+        if (rtiow::debug_knob("RTIOW_DEBUG_HIST")) {  // diagnostic builds: when waves ran dry / finished, 0.125 ms bins
             fprintf(stderr, "waves dry :");
             for (int k = 0; k < 32; ++k) fprintf(stderr, " %u", ctx->h_counters->hist_dry[k]);
             fprintf(stderr, "\nwaves done:");
@@ -652,6 +657,35 @@ int rtClusterBuildHost(const RtSphere* spheres, uint32_t n_spheres, float range_
     }
     if (slot_index)
         for (uint32_t k = 0; k < cs.idx.size() && k < slot_cap; ++k) slot_index[k] = cs.idx[k];
+    return RT_OK;
+}
+
+int rtSceneClusterSelfTestHost(const RtSphere* spheres, uint32_t n_spheres, uint32_t* builds_out, double* range_out,
+                               uint32_t* n_super_out) {
+    if (!spheres || n_spheres == 0 || !builds_out || !range_out || !n_super_out)
+        return fail(nullptr, RT_ERR_INVALID, "rtSceneClusterSelfTestHost: null argument or empty scene");
+    const unsigned long long before = rtiow::cluster_build_count();
+    rtiow::ClusterScene cs;
+    rtiow::build_scene_clusters(spheres, n_spheres, cs);  // the very function rtSetScene calls
+    *builds_out = static_cast<uint32_t>(rtiow::cluster_build_count() - before);
+    *range_out = cs.range_diags;
+    *n_super_out = cs.n_super;
+    return RT_OK;
+}
+
+int rtGetSceneStats(const RtContext* ctx, RtSceneStats* out) {
+    if (!ctx || !out) return fail(nullptr, RT_ERR_INVALID, "rtGetSceneStats: null argument");
+    *out = RtSceneStats{};
+    out->scene_build_ms = ctx->scene_build_ms;
+    out->last_cluster_build_ms = ctx->last_cluster_build_ms;
+    out->range_diags = ctx->cluster_range;
+    out->base_range_diags = ctx->scene_base_range;
+    out->cluster_builds = ctx->cluster_uploads;
+    out->n_clusters = ctx->n_clusters;
+    out->n_super = ctx->n_super;
+    out->n_large = ctx->n_large;
+    out->flat_axis = ctx->flat_axis;
+    out->n_spheres = ctx->n_spheres;
     return RT_OK;
 }
 

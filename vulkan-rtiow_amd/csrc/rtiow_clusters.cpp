@@ -19,6 +19,7 @@
 //     diagonals, more when the camera stands farther out: range_diags); the kernel sends a ray that
 //     starts beyond rmax through all clusters.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -37,7 +38,11 @@ float round_up(double v) {  // smallest float >= v
 }
 }  // namespace
 
+static std::atomic<unsigned long long> g_cluster_builds{0};
+unsigned long long cluster_build_count() { return g_cluster_builds.load(); }
+
 void build_clusters(const RtSphere* sph, uint32_t n, double range_diags, ClusterScene& out) {
+    g_cluster_builds.fetch_add(1);
     out.slots.clear();
     out.idx.clear();
     out.bounds.clear();
@@ -66,9 +71,17 @@ void build_clusters(const RtSphere* sph, uint32_t n, double range_diags, Cluster
     }
     const double diag = std::sqrt(diag2);
     out.diag = static_cast<float>(diag);
+    // (the padded cluster count, as computed below; more than super_from of them: a level of super-clusters above)
+    uint32_t super_from = kSuperFrom;
+    if (const char* v = debug_knob("RTIOW_DEBUG_SUPER_FROM")) super_from = static_cast<uint32_t>(std::strtoul(v, nullptr, 10));  // tuning only
+    const size_t clusters_to_be = ((small.size() + kClusterSize - 1u) / kClusterSize + kSuperSize - 1u) / kSuperSize * kSuperSize;
+    const bool with_supers = clusters_to_be > super_from;
+    // range_diags <= 0: the scene's own range -- kRangeTwoLevel for one with super-clusters, kRangeOneLevel otherwise (rtiow_device.h)
+    if (!(range_diags > 0.0)) range_diags = with_supers ? kRangeTwoLevel : kRangeOneLevel;
+    out.range_diags = std::max(kRangeFloor, range_diags);
     // rays that start within rmax of the centre use the boxes; |oc| <= rmax + diag/2 for them
-    double rmax = std::max(kRangeFloor, range_diags) * diag;
-    if (const char* v = std::getenv("RTIOW_DEBUG_RANGE")) rmax = std::atof(v) * diag;  // tuning only (tools/range_ab.py)
+    double rmax = out.range_diags * diag;
+    if (const char* v = debug_knob("RTIOW_DEBUG_RANGE")) rmax = std::atof(v) * diag;  // tuning only (tools/range_ab.py)
     out.rmax2 = static_cast<float>(rmax * rmax);
     constexpr double kEps = 5.9604644775390625e-8;  // 2^-24
     const double oc_max = rmax * 1.05 + 0.5 * diag;  // rmax + diag/2, and the rounding of the kernel's own range check
@@ -87,11 +100,6 @@ void build_clusters(const RtSphere* sph, uint32_t n, double range_diags, Cluster
     // Morton curve give boxes a ray meets 2.1x as often on the cover scene: tools/cull_sim.py.)
     struct Range { size_t lo, hi; };
     constexpr size_t kSuperSpan = size_t(kSuperSize) * kClusterSize;  // spheres under one super-cluster
-    uint32_t super_from = kSuperFrom;
-    if (const char* v = std::getenv("RTIOW_DEBUG_SUPER_FROM")) super_from = static_cast<uint32_t>(std::strtoul(v, nullptr, 10));  // tuning only
-    // (the padded cluster count, as computed below)
-    const size_t clusters_to_be = ((small.size() + kClusterSize - 1u) / kClusterSize + kSuperSize - 1u) / kSuperSize * kSuperSize;
-    const bool with_supers = clusters_to_be > super_from;
     std::vector<Range> todo{{0, small.size()}};
     while (!todo.empty()) {
         const Range rg = todo.back();
@@ -226,7 +234,7 @@ void build_clusters(const RtSphere* sph, uint32_t n, double range_diags, Cluster
     out.flat_axis = 3u;
     out.flat_mid = out.flat_half = 0.0f;
     if (n_real_clusters > 0u) {
-        const char* force = std::getenv("RTIOW_DEBUG_FLAT");  // (1: every scene flat along its best axis -- parity tests only)
+        const char* force = debug_knob("RTIOW_DEBUG_FLAT");  // (1: every scene flat along its best axis -- parity tests only)
         double best_ratio = force && std::atoi(force) == 1 ? 1e300 : 1.5;
         for (uint32_t axis = 0; axis < 3u; ++axis) {
             double lo = 1e300, hi = -1e300, narrowest = 1e300;
@@ -257,6 +265,12 @@ void build_clusters(const RtSphere* sph, uint32_t n, double range_diags, Cluster
             out.bounds.push_back(ClusterF4{m[ia], m[ib], h[ia], h[ib]});
         }
     }
+}
+
+void build_scene_clusters(const RtSphere* spheres, uint32_t n, ClusterScene& out) {
+    build_clusters(spheres, n, 0.0, out);  // the scene's own range, decided before a box is made: one build
+    if (out.n_super != 0u && clustered_levels_that_fit(static_cast<uint32_t>(out.slots.size()), out.n_clusters, out.n_super, out.flat_axis < 3u) == 1)
+        build_clusters(spheres, n, kRangeOneLevel, out);  // (the kernels will drop the super level: boxes for a one-level trace)
 }
 
 }  // namespace rtiow

@@ -43,6 +43,10 @@ struct RtContext {
     uint32_t last_kernel = 0;     // variant the last PATH render launched
     std::vector<RtSphere> host_spheres;  // kept to re-box the clusters for a camera farther out
     double cluster_range = 0;     // range_diags the current boxes were built for
+    double scene_base_range = 0;  // the scene's own range (kRangeOneLevel / kRangeTwoLevel), chosen by rtSetScene
+    uint32_t cluster_uploads = 0; // times the lists of the current scene were built and uploaded (1 after rtSetScene; + re-boxes)
+    double scene_build_ms = 0;    // host time of the last rtSetScene (shading records, cluster build, uploads)
+    double last_cluster_build_ms = 0;  // ... and of the last cluster build + upload alone (rtSetScene or a re-box in rtRender)
     uint32_t n_spheres = 0;
     rtiow::Counters* d_counters = nullptr;  // TWO blocks: frame k counts in block k & 1 and its last workgroup zeroes the other
     uint32_t counter_index = 0;             // the block the next PATH frame uses ...

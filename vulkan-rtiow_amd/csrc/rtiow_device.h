@@ -3,11 +3,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/rtiow.h"
 
 namespace rtiow {
+
+// Tuning and test knobs (RTIOW_DEBUG_* environment variables) exist in the diagnostic builds only -- -DRTIOW_DEBUG_KNOBS:
+// librtiow_hip_knobs.so (the shipped kernels + the knobs: what the A/B tools and two parity tests load) and librtiow_hip_dbg.so.
+// The shipped library never reads the environment on its render path: no variable can change its kernel choice, and a frame's
+// dispatch makes no getenv calls (rounds 1-3: about a dozen per frame).
+#ifdef RTIOW_DEBUG_KNOBS
+inline const char* debug_knob(const char* name) { return std::getenv(name); }
+#else
+inline const char* debug_knob(const char*) { return nullptr; }
+#endif
 
 // Device-side counters, one block per context (zeroed before every render).
 // Head of one per-XCD pixel queue, alone on its 128-byte line: atomics on one line are serialised by
@@ -27,6 +38,8 @@ struct Counters {
     unsigned long long segments;
     unsigned long long tests;       // ray-sphere and ray-bound tests performed
     unsigned long long debug[8];    // diagnostic builds (-DRTIOW_DEBUG_COUNTERS) only
+    unsigned long long clk_cycles, clk_ticks;  // persistent kernels: shader cycles and ticks of the constant 100 MHz counter the first wave
+                                    // of workgroup 0 saw from its start to its end -> RtStats.shader_clock_mhz
     unsigned long long not_t0;      // diagnostic builds: ~(earliest wave start), 100 MHz ticks
     unsigned int hist_dry[32];      // diagnostic builds: waves by the time their queue ran dry, 0.125 ms bins
     unsigned int hist_end[32];      // diagnostic builds: waves by the time they finished
@@ -131,6 +144,27 @@ struct ChArgs {
     uint32_t vector_store;   // (set by launch_ch) destination rows are 16-byte aligned
 };
 
+// Chunks of the persistent kernels' pixel queue.  One chunk = 32 pixels = one 128-byte line of the frame: all its
+// stores come from the XCD whose queue holds it.  Also the unit of the cost order: measured on the cover frame, one
+// eighth of it (tools/ab_bench.py): 256 pixels 1.71 ms, 128: 1.67, 64: 1.69, 32: 1.64 (32 without the order: 1.72);
+// whole frame 10.31-10.40 either way.
+#ifndef RTIOW_CHUNK_PIX
+#define RTIOW_CHUNK_PIX 32
+#endif
+constexpr uint32_t kChunkPixels = RTIOW_CHUNK_PIX;
+// LDS a wave of the persistent kernels has to itself (rtiow_kernels.hip: path_persistent_kernel lays it out, launch_path sizes it)
+constexpr uint32_t kChunkPix = kChunkPixels;         // pixels per XCD-queue chunk: 32 = one 128-byte line of the frame
+constexpr uint32_t kLineBufs = 4;                    // whole chunks a wave may be assembling: 32 RGBA8 pixels each +
+constexpr uint32_t kLineMetaWords = 4;               // ... {pixels done, pixels expected, segments they took (u64)}
+constexpr uint32_t kWaveLineBytes = kLineBufs * (kChunkPix + kLineMetaWords) * 4u;
+constexpr uint32_t kAccEntries = 64;                 // pixels a wave may have in flight
+constexpr uint32_t kAccWords = 4;                    // u64 words per entry: r, g, b, samples done
+constexpr uint32_t kWaveAccBytes = kAccEntries * kAccWords * 8u;  // 2 KiB of LDS per wave
+constexpr uint32_t kWavePixBytes = kAccEntries * 4u;              // ... and the pixel of each entry
+constexpr uint32_t kItemCap = 512;                   // (clustered) items per work list
+constexpr uint32_t kWaveResultBytes = 128u * 8u;     // (clustered) one u64 key per path slot of the wave
+__host__ __device__ constexpr uint32_t wave_item_bytes(bool two_level) { return kWaveResultBytes + kItemCap * 2u * (two_level ? 2u : 1u); }
+constexpr size_t kLdsPerCu = 160u * 1024u - 256u;    // (the kernels' static __shared__ words come on top of the dynamic part)
 // kernel variants selectable through RtParams.kernel (identical results)
 struct ClusterF4 {
     float x, y, z, w;
@@ -149,6 +183,7 @@ struct ClusterScene {  // host-side result of build_clusters
     float rmax2 = 0;              // (range_diags diag)^2: ray origins farther from the centre are outside
                                   // the rounding margin the boxes were inflated for
     float far_k = 0, far_c = 0;   // a ray that starts q from the centre may use the boxes enlarged by far_k q + far_c
+    double range_diags = 0;       // the range the boxes were built for, in scene diagonals (what rmax2 came from)
 };
 // The range the boxes of a scene are inflated for, in scene diagonals from its centre, while the camera is within it (rtRender moves
 // up a rung when it is not: range_for_camera): 2 for a scene with one level of boxes -- a ray from beyond costs its wave-wide test
@@ -157,8 +192,23 @@ struct ClusterScene {  // host-side result of build_clusters
 // range times the scene's extent, are what inflates the boxes: C5's scene 7.60 -> 6.96 ms at 64 spp, 53.0 -> 47.1 tests per segment
 // (tools/range_ab.py; 0.5 diagonals are the scene's own bounding sphere, below that the camera rays' culls go).
 constexpr double kRangeOneLevel = 2.0, kRangeTwoLevel = 0.6, kRangeFloor = 0.25;
-// range_diags: ray origins up to this many scene diagonals from the scene's centre use the boxes (>= kRangeFloor)
+// range_diags: ray origins up to this many scene diagonals from the scene's centre use the boxes (>= kRangeFloor); <= 0: the
+// scene's own range -- kRangeTwoLevel if it gets super-clusters, kRangeOneLevel if not -- decided inside, before a box is made
 void build_clusters(const RtSphere* spheres, uint32_t n, double range_diags, ClusterScene& out);
+unsigned long long cluster_build_count();  // calls of build_clusters in this process so far (tests: a scene is boxed once)
+// Does the clustered list fit the LDS of a CU beside the per-wave areas of one 256-thread group: 2 = with its super-cluster
+// level, 1 = without it (launch_path then drops the level), 0 = not at all (flat list).  Shared by launch_path and rtSetScene.
+inline int clustered_levels_that_fit(uint32_t n_cslots, uint32_t n_clusters, uint32_t n_super, bool flat) {
+    const uint32_t box_bytes = flat ? 16u : 32u;
+    auto fits = [&](uint32_t supers) {
+        return static_cast<size_t>(n_cslots) * 20u + static_cast<size_t>(n_clusters + supers) * box_bytes +
+                   4u * (kWaveAccBytes + kWavePixBytes + kWaveLineBytes + wave_item_bytes(supers != 0u)) <= kLdsPerCu;
+    };
+    return fits(n_super) ? 2 : (fits(0u) ? 1 : 0);
+}
+// The lists rtSetScene uploads: built for the scene's own range -- and, when its super-cluster level will not fit the LDS (a band of
+// a few thousand spheres just below the flat-list fallback), for the one-level range instead, since launch_path will trace one level.
+void build_scene_clusters(const RtSphere* spheres, uint32_t n, ClusterScene& out);
 
 // PATH mode: the persistent kernels count a path's segments in 19 bits of its slot's bookkeeping word (rtiow_kernels.hip, Slot)
 constexpr uint32_t kMaxPathDepth = (1u << 19) - 1u;
@@ -181,14 +231,6 @@ int cone_selftest_host(const RtCamera& cam, uint32_t width, uint32_t height, uin
 // `resolved` receives the variant that was launched (KERNEL_DEFAULT resolves to one of the others)
 hipError_t launch_path(const PathArgs& a, uint32_t kernel, uint32_t max_take, int num_cus,
                        hipStream_t stream, uint32_t* resolved);
-// Chunks of the persistent kernels' pixel queue.  One chunk = 32 pixels = one 128-byte line of the frame: all its
-// stores come from the XCD whose queue holds it.  Also the unit of the cost order: measured on the cover frame, one
-// eighth of it (tools/ab_bench.py): 256 pixels 1.71 ms, 128: 1.67, 64: 1.69, 32: 1.64 (32 without the order: 1.72);
-// whole frame 10.31-10.40 either way.
-#ifndef RTIOW_CHUNK_PIX
-#define RTIOW_CHUNK_PIX 32
-#endif
-constexpr uint32_t kChunkPixels = RTIOW_CHUNK_PIX;
 inline uint32_t chunk_count(uint32_t local_rows, uint32_t width) {
     return static_cast<uint32_t>((static_cast<unsigned long long>(local_rows) * width + kChunkPixels - 1u) / kChunkPixels);
 }

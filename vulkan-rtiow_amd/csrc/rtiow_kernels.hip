@@ -739,14 +739,6 @@ constexpr uint32_t kSparseMax = RTIOW_SPARSE_MAX; // live paths per wave at or b
 #define RTIOW_SPARSE_MAX_ACCEL 32  // all paths together (trace_sparse_parallel)
 #endif
 constexpr uint32_t kSparseMaxAccel = RTIOW_SPARSE_MAX_ACCEL;  // the same for the clustered list (cluster-parallel trace)
-constexpr uint32_t kChunkPix = kChunkPixels;         // pixels per XCD-queue chunk: 32 = one 128-byte line of the frame
-constexpr uint32_t kLineBufs = 4;                    // whole chunks a wave may be assembling: 32 RGBA8 pixels each +
-constexpr uint32_t kLineMetaWords = 4;               // ... {pixels done, pixels expected, segments they took (u64)}
-constexpr uint32_t kWaveLineBytes = kLineBufs * (kChunkPix + kLineMetaWords) * 4u;
-constexpr uint32_t kAccEntries = 64;                 // pixels a wave may have in flight
-constexpr uint32_t kAccWords = 4;                    // u64 words per entry: r, g, b, samples done
-constexpr uint32_t kWaveAccBytes = kAccEntries * kAccWords * 8u;  // 2 KiB of LDS per wave
-constexpr uint32_t kWavePixBytes = kAccEntries * 4u;              // ... and the pixel of each entry
 
 // Bookkeeping of a path in flight, ONE register: its pixel's accumulator entry (one of its wave's kAccEntries; the field has 10 bits),
 // the line buffer of its chunk + 1 (0: the pixel goes straight to the frame: 3 bits) and the segments it has taken
@@ -1054,9 +1046,6 @@ HDI float slab_rcp(float d) {  // reciprocal of a direction component kept away 
 // Per-wave LDS of the clustered trace: the per-ray result keys, the (ray, cluster) work list of phase 2
 // and, for scenes with super-clusters, the (ray, super-cluster) list before it.
 constexpr uint32_t kLargeLockstep = 8;  // up to this many large spheres take the exact test in lock-step (trace_clustered)
-constexpr uint32_t kItemCap = 512;  // items per list
-constexpr uint32_t kWaveResultBytes = 128u * 8u;  // one u64 key per path slot of the wave
-__host__ __device__ constexpr uint32_t wave_item_bytes(bool two_level) { return kWaveResultBytes + kItemCap * 2u * (two_level ? 2u : 1u); }
 
 // makes the fourth component of a float4 read from LDS count as used, so that the read stays one ds_read_b128
 DI void keep_b128(const float4& v) { asm volatile("" ::"v"(v.w)); }
@@ -2294,6 +2283,14 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     __shared__ unsigned int wg_left;           // how many have
     if (threadIdx.x < 3u) wg_sums[threadIdx.x] = 0ull;
     if (threadIdx.x == 3u) wg_left = 0u;
+    // The shader clock this frame ran at, from one wave's two clocks (shader cycles, and the constant 100 MHz counter): the stamps
+    // are parked in LDS, not in registers.  (The fp32 peak a frame can be rated against is 157.3 TFLOP/s at 2.4 GHz;
+    // under this kernel the part holds about 2.0: bench.py prints both.)
+    __shared__ unsigned long long clk_start[2];
+    if (threadIdx.x == 0u) {
+        clk_start[0] = __builtin_readcyclecounter();
+        clk_start[1] = wall_clock64();
+    }
     uint32_t* lds_cidx = reinterpret_cast<uint32_t*>(lds_spheres + g.n_pad);
     float4* lds_cbounds = reinterpret_cast<float4*>(lds_cidx + (ACCEL ? g.n_pad : 0u));
     // (boxes: centre + half extent, two float4 each; FLAT: without the flat axis, one float4 each)
@@ -3045,6 +3042,10 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             last_group = __hip_atomic_fetch_add(&a.counters->wg_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x;
         }
     }
+    if (blockIdx.x == 0u && threadIdx.x == 0u) {  // (its own stamps: written by this very lane)
+        a.counters->clk_cycles = __builtin_readcyclecounter() - clk_start[0];  // (rtGetStats divides)
+        a.counters->clk_ticks = wall_clock64() - clk_start[1];
+    }
     last_group = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(last_group)) != 0u;
     if (last_group && a.next_counters != nullptr) {
         uint32_t* words = reinterpret_cast<uint32_t*>(a.next_counters);
@@ -3238,7 +3239,7 @@ hipError_t launch_ch(const ChArgs& args, hipStream_t stream) {
     // the lean square roots and quotients (lean_sqrt, lean_div) for a camera of moderate proportions, hipcc's full forms otherwise
     auto moderate = [](float v) { return std::fabs(v) >= 0x1p-20f && std::fabs(v) <= 0x1p20f; };
     const bool lean = moderate(a.ubo.viewportWidth) && moderate(a.ubo.viewportHeight) && moderate(a.ubo.focalLength) &&
-                      !getenv("RTIOW_DEBUG_CH_FULL");  // (the variable: A/B and parity tests)
+                      !debug_knob("RTIOW_DEBUG_CH_FULL");  // (the variable: A/B and parity tests)
     if (lean) hipLaunchKernelGGL(ch_kernel_rows<true>, dim3(blocks), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(ch_kernel_rows<false>, dim3(blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
@@ -3327,20 +3328,18 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // default: the clustered list from kClusteredFrom spheres on (cover scene: 2.1x faster than the
     // flat list; frames are byte-identical either way), the flat list for the handful-of-spheres scenes
     bool accel = kernel == KERNEL_CLUSTERED || kernel == KERNEL_CLUSTERED_PASS || (kernel == KERNEL_DEFAULT && a.n >= kClusteredFrom);
-    constexpr size_t kLdsPerCu = 160u * 1024u - 256u;  // (the kernel's static __shared__ words come on top of the dynamic part)
     // The clustered list must fit the LDS beside four waves' buffers.  The very largest scenes give up
     // the super-cluster level first (its boxes and second work list), then fall back to the flat list.
     // the flat axis (rtiow_clusters.cpp): RTIOW_DEBUG_FLAT=0 tests the whole boxes all the same (A/B and parity tests;
     // RTIOW_DEBUG_FLAT=1, read by rtSetScene, makes every scene flat along its best axis)
-    if (!accel || (getenv("RTIOW_DEBUG_FLAT") && atoi(getenv("RTIOW_DEBUG_FLAT")) == 0)) a.flat_axis = 3u;
+    if (!accel || (debug_knob("RTIOW_DEBUG_FLAT") && atoi(debug_knob("RTIOW_DEBUG_FLAT")) == 0)) a.flat_axis = 3u;
     const bool flat = a.flat_axis < 3u;
     const uint32_t box_bytes = flat ? 16u : 32u;  // (LDS per box: without the flat axis one float4 instead of two)
-    auto clustered_fits = [&](uint32_t n_super) {
-        return static_cast<size_t>(a.n_cslots) * 20u + static_cast<size_t>(a.n_clusters + n_super) * box_bytes +
-                   4u * (kWaveAccBytes + kWavePixBytes + kWaveLineBytes + wave_item_bytes(n_super != 0u)) <= kLdsPerCu;  // at least one 256-thread group
-    };
-    if (accel && !clustered_fits(a.n_super)) a.n_super = 0u;
-    if (accel && !clustered_fits(0u)) accel = false;
+    if (accel) {
+        const int levels = clustered_levels_that_fit(a.n_cslots, a.n_clusters, a.n_super, flat);
+        if (levels < 2) a.n_super = 0u;
+        if (levels < 1) accel = false;
+    }
     const uint32_t item_bytes = wave_item_bytes(a.n_super != 0u);
     *resolved = accel ? KERNEL_CLUSTERED : KERNEL_PERSISTENT;
     PersistArgs g{};
@@ -3355,7 +3354,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     pool_samples = pool_samples < 256u ? 256u : (pool_samples > 4096u ? 4096u : pool_samples);
     g.pool_pix = pool_samples / a.spp;  // a few pixels per pool; one pixel when spp is large
     g.pool_pix = g.pool_pix < 1u ? 1u : (g.pool_pix > 256u ? 256u : g.pool_pix);
-    if (const char* v = getenv("RTIOW_DEBUG_POOL_PIX")) g.pool_pix = strtoul(v, nullptr, 10);  // tuning only
+    if (const char* v = debug_knob("RTIOW_DEBUG_POOL_PIX")) g.pool_pix = strtoul(v, nullptr, 10);  // tuning only
     // LDS per workgroup: the sphere list (16 B per slot; clustered: + 4 B per slot of indices and
     // 32 B per cluster box); while the scene is small, the shading records too (32 B each);
     // 2 KiB of pixel accumulator entries and 0.5 KiB of line buffers per wave (clustered: + 2-3 KiB of work lists
@@ -3365,7 +3364,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // (a scene with super-clusters -- more than kSuperFrom clusters, i.e. more than 512 small spheres: 30 KB at least -- is never a
     // small one: the small-scene kernels are compiled without that level)
     const bool shade_lds = a.n_super == 0u && lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 28u * 1024u &&
-                           !getenv("RTIOW_DEBUG_NO_SHADE_LDS");  // (tuning only)
+                           !debug_knob("RTIOW_DEBUG_NO_SHADE_LDS");  // (tuning only)
     const size_t lds_scene = lds_geo + (shade_lds ? static_cast<size_t>(a.n) * sizeof(ShadeRec) : 0u);
     // the clustered kernels' primary pass keeps up to pass_keep camera paths per wave in LDS records of their own; a
     // large scene with no room for them (C5: one 768-thread group beside 92 KB of list) does without -- its passes then
@@ -3383,12 +3382,12 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     uint32_t threads = 0u;
     int per_cu = 0;
     size_t lds = 0u;
-    const uint32_t pinned = getenv("RTIOW_DEBUG_THREADS") ? strtoul(getenv("RTIOW_DEBUG_THREADS"), nullptr, 10) : 0u;
+    const uint32_t pinned = debug_knob("RTIOW_DEBUG_THREADS") ? strtoul(debug_knob("RTIOW_DEBUG_THREADS"), nullptr, 10) : 0u;
     // (the small-scene variant of the clustered kernel is compiled for groups of at most 512: with the bound at
     // 768 the same source came out 3 % slower on the cover frame)
     const uint32_t t_max = accel ? (shade_lds ? static_cast<uint32_t>(RTIOW_SMALL_MAX_THREADS) : static_cast<uint32_t>(kAccelMaxThreads)) : 1024u;
     uint32_t keep_env = kPassKeep;
-    if (const char* v = getenv("RTIOW_DEBUG_PASS_KEEP")) keep_env = strtoul(v, nullptr, 10) ? kPassKeep : 0u;  // tuning only
+    if (const char* v = debug_knob("RTIOW_DEBUG_PASS_KEEP")) keep_env = strtoul(v, nullptr, 10) ? kPassKeep : 0u;  // tuning only
     for (int pass = 0; pass < 2; ++pass) {  // with the records first; without them only if that keeps more waves on a CU
         const uint32_t keep = accel && pass == 0 ? keep_env : 0u;
         if (pass == 1 && (!accel || keep_env == 0u)) break;  // (nothing new to try)
@@ -3415,14 +3414,14 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // of its two-level culls for a handful of rays costs more than the slots it fills; cover scenes of 1026 / 1938 / 3138 spheres
     // 5.78 -> 5.48, 6.73 -> 6.61, 7.52 -> 7.28 ms at 64 spp, tools/keep_ab.py)
     if (!shade_lds && g.pass_keep != 0u && g.pass_min_idle < 16u) g.pass_min_idle = 16u;
-    if (const char* v = getenv("RTIOW_DEBUG_PASS_MIN_IDLE")) g.pass_min_idle = strtoul(v, nullptr, 10);  // tuning only
+    if (const char* v = debug_knob("RTIOW_DEBUG_PASS_MIN_IDLE")) g.pass_min_idle = strtoul(v, nullptr, 10);  // tuning only
     g.pass_cap = g.pass_keep + item_bytes / kPassRecBytes;
     if (g.pass_cap > 64u) g.pass_cap = 64u;
     if (accel) {
         const bool cull = cone_setup(a, g);
         g.use_pass = kernel == KERNEL_CLUSTERED_PASS ||
-                     a.spp >= (getenv("RTIOW_DEBUG_PASS_MIN_SPP") ? strtoul(getenv("RTIOW_DEBUG_PASS_MIN_SPP"), nullptr, 10) : kPassMinSpp) ? 1u : 0u;
-        g.primary_all = (cull && !getenv("RTIOW_DEBUG_NO_CONE")) ? 0u : 1u;
+                     a.spp >= (debug_knob("RTIOW_DEBUG_PASS_MIN_SPP") ? strtoul(debug_knob("RTIOW_DEBUG_PASS_MIN_SPP"), nullptr, 10) : kPassMinSpp) ? 1u : 0u;
+        g.primary_all = (cull && !debug_knob("RTIOW_DEBUG_NO_CONE")) ? 0u : 1u;
     }
     if (threads == 0u) return hipErrorInvalidValue;  // rtSetScene's sphere limit keeps this from happening
     // persistent grid: fill the chip once; never more slots than samples
@@ -3430,7 +3429,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     const unsigned long long samples = static_cast<unsigned long long>(g.total_pix) * a.spp;
     const unsigned long long want_blocks = (samples + threads * kSlots - 1) / (threads * kSlots);
     if (grid > want_blocks) grid = want_blocks;
-    if (const char* v = getenv("RTIOW_DEBUG_GRID")) grid = strtoul(v, nullptr, 10);  // tuning only
+    if (const char* v = debug_knob("RTIOW_DEBUG_GRID")) grid = strtoul(v, nullptr, 10);  // tuning only
     if (grid < 1) grid = 1;
     g.total_waves = static_cast<uint32_t>(grid) * (threads / 64u);
     // A pool is never more than a share of what a wave gets in all: pools are of one size to the end of a queue (no look
@@ -3438,7 +3437,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // wave, was dealt in pools of 40 and took 1.93 ms instead of 0.8 (RTIOW_DEBUG_POOL_SHARE: tuning only).
     {
         uint32_t share = 4u;
-        if (const char* v = getenv("RTIOW_DEBUG_POOL_SHARE")) share = strtoul(v, nullptr, 10);
+        if (const char* v = debug_knob("RTIOW_DEBUG_POOL_SHARE")) share = strtoul(v, nullptr, 10);
         const uint32_t cap = share ? g.total_pix / (g.total_waves * share) : ~0u;
         if (g.pool_pix > (cap < 1u ? 1u : cap)) g.pool_pix = cap < 1u ? 1u : cap;
     }
@@ -3456,12 +3455,12 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // a dear chunk may come last and its wave finish alone: the first frame of a shape took 10.9-11.1 ms with whole
     // chunks against 10.5 without (9.6 once the order is there).
     if (a.chunk_order == nullptr) g.chunk_until = ~0u;
-    if (const char* v = getenv("RTIOW_DEBUG_CHUNK_UNTIL")) g.chunk_until = strtoul(v, nullptr, 10);
+    if (const char* v = debug_knob("RTIOW_DEBUG_CHUNK_UNTIL")) g.chunk_until = strtoul(v, nullptr, 10);
     // ... and where no whole chunks are handed out -- small frames -- the head of an ORDERED queue, its dearest eighth, goes out
     // pixel by pixel (see the fetch): a queue has total_pix / 8 pixels (RTIOW_DEBUG_FINE_DIV: tuning only; 0 switches it off)
     {
         uint32_t div = 8u;
-        if (const char* v = getenv("RTIOW_DEBUG_FINE_DIV")) div = strtoul(v, nullptr, 10);
+        if (const char* v = debug_knob("RTIOW_DEBUG_FINE_DIV")) div = strtoul(v, nullptr, 10);
         g.fine_pix = 128u / a.spp < 1u ? 1u : 128u / a.spp;  // (a 1-spp frame: 128 pixels -- more than its pools hold, i.e. no fine dealing)
         g.fine_until = (g.chunk_until == ~0u && a.chunk_order != nullptr && div != 0u && g.pool_pix > g.fine_pix) ? g.total_pix / 8u / div : 0u;
     }

@@ -113,9 +113,18 @@ def fail_loudly(what: str = "multi-GPU frame"):
     a non-zero code at once (os._exit: no communicator destructors, which may wait for peers that are themselves stuck
     in the collective this rank never joined).  The launcher (torch.distributed.run) then tears the other ranks down,
     and a peer left inside a collective fails on its own once this rank's sockets close or the process group's timeout
-    expires -- it never completes a different collective instead."""
+    expires -- it never completes a different collective instead.  A clean exit (SystemExit with code 0 or None) passes
+    through untouched.  os._exit skips Python's cleanup: files the wrapped code writes must be closed (or written with
+    `with open(...)`) before an error can occur -- only stdout and stderr are flushed here."""
     try:
         yield
+    except SystemExit as exc:
+        if exc.code in (0, None):
+            raise  # a clean exit is not a failure
+        sys.stderr.write(f"[rank {os.environ.get('RANK', '?')}] {what} exited with status {exc.code}\n")
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(exc.code if isinstance(exc.code, int) and 0 < exc.code < 256 else 13)
     except BaseException as exc:  # noqa: BLE001 (KeyboardInterrupt too: the peers must not be left waiting)
         import traceback
         r = os.environ.get("RANK", "?")

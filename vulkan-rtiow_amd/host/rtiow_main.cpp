@@ -244,9 +244,12 @@ int main(int argc, char** argv) {
         for (size_t g = 0; g < sum_dev_ms.size(); ++g) std::printf("%s%.4f", g ? ", " : "", sum_dev_ms[g] / steps);
         std::printf("], \"devices\": [");
         for (size_t g = 0; g < sum_dev_ms.size(); ++g) std::printf("%s%d", g ? ", " : "", devices.empty() ? device : devices[g]);
+        RtSceneStats ss{};
+        if (!multi && ctx) rtGetSceneStats(ctx, &ss);  // (single device: what rtSetScene cost and chose)
         std::printf("], \"segments_per_frame\": %llu, \"sphere_tests_per_frame\": %llu, \"frame_crc32\": %u, "
+                    "\"scene_build_ms\": %.3f, \"cluster_builds\": %u, \"cluster_range_diags\": %.3g, "
                     "\"gathered_frame_vs_single_gpu_frame\": \"%s\"}}\n",
-                    last_segments, last_tests, crc, vs_single);
+                    last_segments, last_tests, crc, ss.scene_build_ms, ss.cluster_builds, ss.range_diags, vs_single);
     }
     const bool png = out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0;
     rc = png ? rtWritePNG(out.c_str(), frame.data(), width, height, size_t(width) * 4)
