@@ -184,6 +184,14 @@ def cold_and_moving_frames(V, torch, dev, device_id, sph, mat, cam, prm, w, h, t
     loop([cam] * 4)
     res["static_camera_same_loop_ms_per_step"] = loop([cam] * n)
     res["moving_camera_ms_per_step"] = loop(cams)
+    # ... the orbit's views are other frames than the timed one (more of the glass ball, other path lengths): what moving costs is
+    # read against the SAME sixteen views, each standing still until its own chunk order is there
+    settled = 0.0
+    for c in cams:
+        loop([c] * 5)
+        settled += loop([c] * 3)
+    res["moving_camera_views_standing_still_ms_per_step"] = settled / n
+    res["moving_camera_penalty"] = res["moving_camera_ms_per_step"] / (settled / n) - 1.0
     res["moving_camera"] = f"{n} frames of an orbit around the look-at point, 3.75 degrees a frame, a new RtCamera every frame"
     bad = 0
     with V.Context(device_id) as fresh:

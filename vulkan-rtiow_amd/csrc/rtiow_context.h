@@ -65,6 +65,7 @@ struct RtContext {
     RtFrameShape order_shape;               // (size, tile) the order belongs to
     bool order_valid = false;
     uint32_t order_frames = 0;              // frames of this shape rendered so far
+    RtCamera order_cam{};                   // the camera of the last of them (a camera that moves has every frame report its costs)
     RtFrameShape accum_shape;               // which frame the accumulators belong to
     uint32_t accum_samples = 0;             // samples accumulated so far
     bool have_timing = false;
