@@ -34,6 +34,7 @@ WORKLOADS = {
     "cover_1200x800_500spp": ("cover", 11, 1200, 800, 500, 50),
     "three_400x225_100spp": ("three", 0, 400, 225, 100, 50),
     "cover4096_3840x2160_1024spp": ("cover", 32, 3840, 2160, 1024, 50),
+    "cover4096_3840x2160_64spp": ("cover", 32, 3840, 2160, 64, 50),   # (C5's scene and frame at a sample count the PMC passes can afford)
     "cover_300x200_10spp": ("cover", 11, 300, 200, 10, 50),
 }
 

@@ -24,4 +24,5 @@ rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F3
     --output-format csv -d $O/prof_${TAG}_lane -- $BENCH > $O/prof_${TAG}_lane.log 2>&1 || true
 cd $R && python3 tools/profile_summary.py $TAG
 #   5. the reference's own kernels at sizes where bytes matter: kernel stats + PMC passes of tools/ch_bandwidth.py
-bash $R/tools/pmc_ch.sh $TAG || true
+#      (third argument "noch": not for this tag -- e.g. the C5 leg: profile.sh r04_c5 "--workload cover4096_3840x2160_64spp" noch)
+if [ "${3:-}" != "noch" ]; then bash $R/tools/pmc_ch.sh $TAG || true; fi

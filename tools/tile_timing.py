@@ -17,10 +17,10 @@ with V.Context(0) as ctx:
         for rank in range(G):
             prm = V.make_params(w, h, spp=spp, max_depth=depth, seed=1, row_block=4, tile_rank=rank, tile_count=G)
             ts = []
-            for _ in range(4):
+            for _ in range(8):
                 ctx.render(cam, prm)
                 ts.append(ctx.stats().kernel_ms)
-            per_rank.append(statistics.median(ts[1:]))
+            per_rank.append(statistics.median(ts[3:]))
         if G == 1:
             full = per_rank[0]
         print(f"G={G}: per-rank kernel ms {['%.2f' % t for t in per_rank]}  max {max(per_rank):.2f}  "

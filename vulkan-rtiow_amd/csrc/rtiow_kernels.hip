@@ -706,6 +706,12 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
 // (tools/ab_bench.py, clustered list, full frame / one eighth of it): 1700 samples 10.97 / 3.00 ms,
 // 850 -> 10.48 / 2.29, 450 -> 10.46 / 2.05, 256 -> 10.5 / 1.95; flat list 29.5 / 5.4 from 256 to 450.
 // launch_path takes kPoolWork / (tests a segment costs) samples, at least 256.
+// Round 4: where a wave's share of the frame is large (8192 samples and more: launch_path) pools are twice that -- the cover frame: nine
+// pixels instead of four -- and never more than an EIGHTH of the share (a quarter elsewhere, as before).  Since the default kernel went to sixteen waves per CU the cover frame has fewer than 256 pixels per
+// wave and hands out no whole chunks any more -- every pixel came from a four-pixel pool, 240 000 queue fetches a frame and, with the
+// dear head of each queue dealt pixel by pixel (which only small frames need: launch_path), 330 000: at ~40 bytes of fabric traffic
+// each they WERE the frame's HBM traffic (15.5 MB against 3.84 MB of pixels: profiles/r04_traffic_experiments.txt), and the waits
+// cost 1.3 % besides: cover frame 6.55 -> 6.47 ms, 2 / 4 / 8 tiles and 16 / 500 spp unchanged (profiles/r04_pool_rule.txt).
 // Tried on top of this and dropped (each cost the full frame 2-7 %): asking for the next pool ahead of
 // time (one atomic in flight per wave); lanes 0-7 looking at all eight heads in one round trip, on every
 // fetch or only once the wave's own queue is dry (the queue-by-queue sweep at the very end of a frame
@@ -3432,11 +3438,21 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     if (const char* v = debug_knob("RTIOW_DEBUG_GRID")) grid = strtoul(v, nullptr, 10);  // tuning only
     if (grid < 1) grid = 1;
     g.total_waves = static_cast<uint32_t>(grid) * (threads / 64u);
-    // A pool is never more than a share of what a wave gets in all: pools are of one size to the end of a queue (no look
+    // A pool is never more than a share (an eighth or a quarter; rounds 2-3: a quarter) of what a wave gets in all: pools are of one size to the end of a queue (no look
     // at the head), and a cheap scene asks for large ones -- the three-sphere frame of BASELINE config 2, 29 pixels per
     // wave, was dealt in pools of 40 and took 1.93 ms instead of 0.8 (RTIOW_DEBUG_POOL_SHARE: tuning only).
     {
-        uint32_t share = 4u;
+        // Where a wave's share of the frame is large -- 8192 samples and more: the cover frame has 23 400, half of it 11 700 -- pools of
+        // twice the work, but no more than an eighth of the share: fewer fetches (each two dependent atomics and ~40 bytes of fabric
+        // traffic: see kPoolWork).  Where it is small -- a quarter or an eighth of the cover frame, a 16-spp frame, 300 x 200 x 10 spp
+        // with its 146 samples per wave -- pools stay as they were: doubled they took one eighth of the cover frame from 1.02 to 1.09 ms,
+        // capped at an eighth the 300 x 200 frame from 0.28 to 0.36 (profiles/r04_pool_rule.txt).
+        const bool large_share = static_cast<unsigned long long>(g.total_pix) * a.spp / g.total_waves >= 8192ull;
+        if (large_share && !debug_knob("RTIOW_DEBUG_POOL_PIX")) {
+            g.pool_pix = 2u * pool_samples / a.spp;
+            g.pool_pix = g.pool_pix < 1u ? 1u : (g.pool_pix > 256u ? 256u : g.pool_pix);
+        }
+        uint32_t share = large_share ? 8u : 4u;
         if (const char* v = debug_knob("RTIOW_DEBUG_POOL_SHARE")) share = strtoul(v, nullptr, 10);
         const uint32_t cap = share ? g.total_pix / (g.total_waves * share) : ~0u;
         if (g.pool_pix > (cap < 1u ? 1u : cap)) g.pool_pix = cap < 1u ? 1u : cap;
@@ -3462,7 +3478,10 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
         uint32_t div = 8u;
         if (const char* v = debug_knob("RTIOW_DEBUG_FINE_DIV")) div = strtoul(v, nullptr, 10);
         g.fine_pix = 128u / a.spp < 1u ? 1u : 128u / a.spp;  // (a 1-spp frame: 128 pixels -- more than its pools hold, i.e. no fine dealing)
-        g.fine_until = (g.chunk_until == ~0u && a.chunk_order != nullptr && div != 0u && g.pool_pix > g.fine_pix) ? g.total_pix / 8u / div : 0u;
+        // (small frames only -- fewer than 48 pixels per wave, one eighth of the cover frame has 29: on larger ones no single pool
+        // is the frame's time, and every fetch is two dependent atomics and ~40 bytes of fabric traffic)
+        const bool small_frame = g.total_pix / g.total_waves < 48u;
+        g.fine_until = (g.chunk_until == ~0u && a.chunk_order != nullptr && div != 0u && g.pool_pix > g.fine_pix && small_frame) ? g.total_pix / 8u / div : 0u;
     }
     hipLaunchKernelGGL(kernel_fn, dim3(static_cast<uint32_t>(grid)), dim3(threads), lds, stream, a, g);
     return hipGetLastError();
