@@ -44,6 +44,9 @@ def test_arith_bit_exact(gpu_ctx, oracle, op, name):
     if op != 7:
         for arr in (a, b, c):  # NaN/inf payloads are outside the contract
             arr[~np.isfinite(arr)] = 1.5
+    if op == 6:   # ... and what a broken path may hand the accumulator: NaN of either sign -> 0, +inf -> the clamp, -inf -> 0
+        a[6000:6008] = np.array([np.nan, -np.nan, np.inf, -np.inf, np.nan, 3.0e38, -3.0e38, np.inf], np.float32)
+        b[6000:6008] = np.array([0.25, np.nan, 0.5, np.inf, np.nan, np.inf, np.nan, -np.inf], np.float32)
     got = gpu_ctx.selftest_arith(op, a, b, c)
     want = oracle.arith(op, a, b, c)
     ok = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))

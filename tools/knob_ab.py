@@ -1,5 +1,5 @@
 """Frame time under settings of the RTIOW_DEBUG_* knobs, interleaved in one process on the knobs build (one context per
-setting: its chunk order is made under that setting).  usage: knob_ab.py [--tile G] [--rank r] [--spp N] [--rounds R] "A=1,B=2" "default" ..."""
+setting: its chunk order is made under that setting).  usage: knob_ab.py [--grid 32 --width 3840 --height 2160] [--tile G] [--rank r] [--spp N] [--rounds R] "A=1,B=2" "default" ..."""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("RTIOW_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vulkan-rtiow_amd", "librtiow_hip_knobs.so"))  # the RTIOW_DEBUG_* knobs exist in this build only
@@ -10,9 +10,9 @@ def opt(name, default):
         i = argv.index(name); v = argv[i + 1]; del argv[i:i + 2]; return int(v)
     return default
 G, spp, rounds, rank = opt("--tile", 1), opt("--spp", 100), opt("--rounds", 9), opt("--rank", 0)
+grid, w, h = opt("--grid", 11), opt("--width", 1200), opt("--height", 800)
 settings = argv or ["default"]
-w, h = 1200, 800
-sph, mat = V.make_cover_scene(1, 11)
+sph, mat = V.make_cover_scene(1, grid)
 cam = V.make_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, w / h, 0.1, 10.0)
 prm = V.make_params(w, h, spp=spp, max_depth=50, seed=1, row_block=4, tile_rank=rank, tile_count=G)
 def apply(s):

@@ -71,9 +71,16 @@ DI uint32_t pack_rgb(uint32_t r, uint32_t g, uint32_t b) { return r | (g << 8) |
 // Multi-sample accumulate (a10): each sample's radiance goes to unsigned 32.32 fixed
 // point (clamp [0,32768], times 2^32 — exact — truncate) and pixels are INTEGER sums,
 // so the result does not depend on which lane added which sample, or in what order.
+// (Six instructions: trunc(c * 2^32) = floor(c) * 2^32 + floor(frac(c) * 2^32) for 0 <= c <= 32768 -- floor(c) and frac(c) = c - floor(c)
+// are exact, the scaling by 2^32 is, and both parts fit 32 bits -- where the compiler's float -> u64 conversion of the same number is ten.
+// fmax(NaN, 0) = 0: the clamp sends a NaN to 0 as the comparisons of the plain form do.)
 DI unsigned long long to_fixed(float x) {
-    const float c = (x > 0.0f) ? (x < 32768.0f ? x : 32768.0f) : 0.0f;  // NaN -> 0
-    return static_cast<unsigned long long>(c * 4294967296.0f);
+    const float c = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 32768.0f);  // NaN -> 0
+    uint32_t hi, lo;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(hi) : "v"(c));  // (truncation; a C cast would be the same here, c being in range)
+    const float f = __builtin_amdgcn_fractf(c) * 4294967296.0f;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(lo) : "v"(f));
+    return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 
 DI uint32_t resolve_pixel(unsigned long long sr, unsigned long long sg, unsigned long long sb,
@@ -2032,11 +2039,9 @@ struct ConeAxis {  // per lane: the cone of the span this half of the wave looks
     bool all;                      // degenerate cone: no cull
 };
 
-HDI ConeAxis cone_of_span(const PathArgs& a, const PersistArgs& g, uint32_t pix_lo, uint32_t pix_hi) {
+// (columns i_lo..i_hi of row j of the frame)
+HDI ConeAxis cone_of_span(const PathArgs& a, const PersistArgs& g, uint32_t i_lo, uint32_t i_hi, uint32_t j) {
     const RtCamera& c = a.cam;
-    const uint32_t lr = pixel_row(a, pix_lo);
-    const uint32_t i_lo = pix_lo - lr * a.width, i_hi = i_lo + (pix_hi - pix_lo);
-    const uint32_t j = tile_global_row(a, lr);
     const float uc = (0.5f * static_cast<float>(i_lo + i_hi) + 0.5f) * a.inv_wm1;
     const float vc = (static_cast<float>(j) + 0.5f) * a.inv_hm1;
     // half the span across, half a pixel up (g.h_len, g.v_len: |horizontal|, |vertical| with their margin)
@@ -2076,8 +2081,7 @@ HDI bool cone_reaches(const PathArgs& a, const PersistArgs& g, const ConeAxis& c
 // of the spans.  Lanes 0-31 look at one span and lanes 32-63 at the next: two spans per evaluation.
 template <bool FLAT>
 DI uint32_t cone_mask(const PathArgs& a, const PersistArgs& g, const float4* bounds, uint32_t base, uint32_t n, uint32_t first,
-                      const ConeAxis& c0, const uint32_t (&span_lo)[kPassSpans], const uint32_t (&span_hi)[kPassSpans],
-                      uint32_t n_spans) {
+                      const ConeAxis& c0) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t b = first + (lane & 31u);
     const bool in = b < n;
@@ -2129,15 +2133,15 @@ DI void exact_keyed_lockstep(const float4* slots, const uint32_t* idx_map, uint3
 // the exact test in lock-step.  Same test, same key, same minimum as trace_clustered for every sphere that can be hit.
 template <bool SUPER, bool FLAT>
 DI void primary_trace(const float4* slots, const uint32_t* idx_map, const float4* bounds, const PathArgs& a,
-                      const PersistArgs& g, const Path& p, bool active, const uint32_t (&span_lo)[kPassSpans],
-                      const uint32_t (&span_hi)[kPassSpans], uint32_t n_spans, float& best, int& best_i,
+                      const PersistArgs& g, const Path& p, bool active, const uint32_t (&span_col)[kPassSpans],
+                      const uint32_t (&span_len)[kPassSpans], const uint32_t (&span_row)[kPassSpans], uint32_t n_spans, float& best, int& best_i,
                       uint32_t& best_o, uint32_t& n_tests, unsigned long long& dbg_trips) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t half = lane & 31u;
     unsigned long long key = ~0ull;
     const bool use_all = g.primary_all != 0u;
     const uint32_t q0 = lane < 32u || n_spans < 2u ? 0u : 1u;
-    const ConeAxis c0 = cone_of_span(a, g, span_lo[q0], span_hi[q0]);
+    const ConeAxis c0 = cone_of_span(a, g, span_col[q0], span_col[q0] + span_len[q0] - 1u, span_row[q0]);
     // one sphere per lane of each half of the wave (slot_of(half): its slot, ~0u: none) against the cones; the spheres
     // that are reached, in lock-step against the rays
     auto spheres = [&](auto&& slot_of) {
@@ -2179,7 +2183,7 @@ DI void primary_trace(const float4* slots, const uint32_t* idx_map, const float4
         for (uint32_t g0 = 0; g0 < a.n_clusters; g0 += 32u) {
             uint32_t cm = 0xFFFFFFFFu;
             if (!use_all) {
-                cm = cone_mask<FLAT>(a, g, bounds, 0u, a.n_clusters, g0, c0, span_lo, span_hi, n_spans);
+                cm = cone_mask<FLAT>(a, g, bounds, 0u, a.n_clusters, g0, c0);
                 n_tests += g0 + half < a.n_clusters ? 1u : 0u;
             }
             if (a.n_clusters - g0 < 32u) cm &= (1u << (a.n_clusters - g0)) - 1u;
@@ -2193,7 +2197,7 @@ DI void primary_trace(const float4* slots, const uint32_t* idx_map, const float4
         for (uint32_t s0 = 0; s0 < a.n_super; s0 += 32u) {
             uint32_t sm = 0xFFFFFFFFu;
             if (!use_all) {
-                sm = cone_mask<FLAT>(a, g, bounds, a.n_clusters, a.n_super, s0, c0, span_lo, span_hi, n_spans);
+                sm = cone_mask<FLAT>(a, g, bounds, a.n_clusters, a.n_super, s0, c0);
                 n_tests += s0 + half < a.n_super ? 1u : 0u;
             }
             if (a.n_super - s0 < 32u) sm &= (1u << (a.n_super - s0)) - 1u;
@@ -2349,7 +2353,8 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     uint32_t pool_xcd = 0u, steal = 0u;      // the queue it came from; queues found dry so far
     const uint32_t xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;  // HW_REG_XCC_ID[3:0]
     const uint32_t n_chunks = (g.total_pix + kChunkPix - 1u) / kChunkPix;
-    uint32_t cur_pix = 0u, cur_entry = 0u;   // pixel being handed out and its accumulator entry
+    uint32_t cur_pix = 0xFFFFFFFEu, cur_entry = 0u;  // pixel being handed out (none yet) and its accumulator entry
+    uint32_t cur_col = 0u, cur_row = 0u;     // ... its column and its row of the frame
     uint32_t cur_seq = ~0u, cur_chunk = 0u;  // position in the chunk sequence the wave is in, and the chunk there
     uint32_t cur_s = a.spp;                  // its next sample; == spp: no pixel open
     unsigned long long free_entries = ~0ull; // accumulator entries not in use
@@ -2497,7 +2502,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     for (;;) {
         [[maybe_unused]] const unsigned long long t0 = DBG_STAMP();
         // ---- refill ---------------------------------------------------------
-        // Hands out the next `want` samples of the wave's pool, pixel by pixel: on_range(first, n, pixel, entry, sample)
+        // Hands out the next `want` samples of the wave's pool, pixel by pixel: on_range(first, n, pixel, column, row, entry, sample)
         // is told that the idle slots numbered first .. first+n-1 get samples sample .. sample+n-1 of that pixel (whose
         // line buffer is cur_line); it may refuse them (false), which ends the call.  Returns how many were handed out
         // (fewer than `want` once the queues are dry or the accumulator entries are all in use).
@@ -2627,6 +2632,15 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     }
                     cur_entry = static_cast<uint32_t>(__builtin_ctzll(free_entries));
                     free_entries &= free_entries - 1ull;
+                    // column and row (of the frame) of the pixel: by one division for the first pixel of a pool or a row, by counting
+                    // for those that follow it (rounds 1-3: two or three divisions per lane and pass, a dozen instructions each)
+                    if (pix == cur_pix + 1u && cur_col + 1u < a.width) {
+                        ++cur_col;
+                    } else {
+                        const uint32_t lr = pixel_row(a, pix);
+                        cur_col = pix - lr * a.width;
+                        cur_row = tile_global_row(a, lr);
+                    }
                     cur_pix = pix;
                     ++pool_next;
                     cur_s = 0u;
@@ -2634,7 +2648,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     if (lane == kAccWords) lds_pix[cur_entry] = pix;
                 }
                 const uint32_t n = want - served < a.spp - cur_s ? want - served : a.spp - cur_s;
-                if (!on_range(served, n, cur_pix, cur_entry, cur_s)) break;  // (the pixel stays open)
+                if (!on_range(served, n, cur_pix, cur_col, cur_row, cur_entry, cur_s)) break;  // (the pixel stays open)
                 cur_s += n;
                 served += n;
             }
@@ -2664,31 +2678,33 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     Slot ps;
                     ps.active = false;
                     ps.meta = 0u;
-                    uint32_t gen_pix = 0u;
+                    uint32_t gen_col = 0u, gen_row = 0u;
                     ps.p.o = ps.p.du = ps.p.att = mk(0.0f, 0.0f, 0.0f);
                     uint32_t gen_s = 0u;
                     // the spans of consecutive pixels (of one row) the pass hands out: wave-uniform
-                    uint32_t span_lo[kPassSpans], span_hi[kPassSpans];
+                    uint32_t span_col[kPassSpans], span_len[kPassSpans], span_row[kPassSpans];  // first column, pixels, row of the frame
 #pragma unroll
-                    for (uint32_t k = 0; k < kPassSpans; ++k) span_lo[k] = span_hi[k] = 0u;
-                    uint32_t n_spans = 0u, last_pix = 0u, row_end = 0u;
+                    for (uint32_t k = 0; k < kPassSpans; ++k) span_col[k] = span_len[k] = span_row[k] = 0u;
+                    uint32_t n_spans = 0u, last_pix = 0u, last_col = 0u;
                     const uint32_t want = n_idle + g.pass_keep < g.pass_cap ? n_idle + g.pass_keep : g.pass_cap;
                     [[maybe_unused]] const unsigned long long th0 = DBG_STAMP();
-                    const uint32_t granted = hand_out(want, [&](uint32_t first, uint32_t n, uint32_t pix, uint32_t entry, uint32_t s0) {
-                        // (wave-uniform) the pixel continues the open span, or opens the next one -- a pass stops at the
-                        // third: lanes 0-31 and 32-63 look at one span each when the cones are tested
-                        const bool extends = n_spans != 0u && pix == last_pix + 1u && pix < row_end;
+                    const uint32_t granted = hand_out(want, [&](uint32_t first, uint32_t n, uint32_t pix, uint32_t col, uint32_t row, uint32_t entry, uint32_t s0) {
+                        // (wave-uniform) the pixel continues the open span (the next pixel of the same row), or opens the next one -- a
+                        // pass stops at the third: lanes 0-31 and 32-63 look at one span each when the cones are tested
+                        const bool extends = n_spans != 0u && pix == last_pix + 1u && col == last_col + 1u;
                         if (!extends && n_spans == kPassSpans) return false;
                         if (extends) {
-                            if (n_spans == 1u) span_hi[0] = pix; else span_hi[1] = pix;
+                            if (n_spans == 1u) ++span_len[0]; else ++span_len[1];
                         } else {
-                            if (n_spans == 0u) span_lo[0] = span_hi[0] = pix; else span_lo[1] = span_hi[1] = pix;
+                            if (n_spans == 0u) { span_col[0] = col; span_len[0] = 1u; span_row[0] = row; }
+                            else { span_col[1] = col; span_len[1] = 1u; span_row[1] = row; }
                             ++n_spans;
-                            row_end = (pixel_row(a, pix) + 1u) * a.width;
                         }
                         last_pix = pix;
+                        last_col = col;
                         if (lane - first < n) {  // (unsigned: first <= lane < first + n)
-                            gen_pix = pix;
+                            gen_col = col;
+                            gen_row = row;
                             ps.meta = meta_of(entry, cur_line);
                             gen_s = s0 + (lane - first);
                         }
@@ -2701,16 +2717,14 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     DBG_ADD(dbg_pass[1], lane == 0u ? granted : 0u);
                     ps.active = lane < granted;
                     if (ps.active) {
-                        const uint32_t lr = pixel_row(a, gen_pix), i = gen_pix - lr * a.width;
-                        const uint32_t j = tile_global_row(a, lr);
-                        camera_path(a, i, j, a.sample_offset + gen_s, ps.p);
+                        camera_path(a, gen_col, gen_row, a.sample_offset + gen_s, ps.p);
                         ++n_paths;
                     }
                     DBG_ADD(dbg_pass[7], lane == 0u ? DBG_STAMP() - tp0 : 0ull);  // camera_path
                     float pb;
                     int pb_i;
                     uint32_t pb_o;
-                    primary_trace<!SHADE_LDS, FLAT>(lds_spheres, lds_cidx, lds_cbounds, a, g, ps.p, ps.active, span_lo, span_hi, n_spans,
+                    primary_trace<!SHADE_LDS, FLAT>(lds_spheres, lds_cidx, lds_cbounds, a, g, ps.p, ps.active, span_col, span_len, span_row, n_spans,
                                               pb, pb_i, pb_o, n_tests, dbg_pass[2]);
                     float4 pr0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pr1 = pr0;
                     if (!SHADE_LDS && ps.active && pb_i >= 0) {
@@ -2779,11 +2793,12 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     bool got[kSlots];
 #pragma unroll
                     for (int r = 0; r < kSlots; ++r) got[r] = false;
-                    uint32_t gen_pix = 0u, gen_s = 0u;
+                    uint32_t gen_col = 0u, gen_row = 0u, gen_s = 0u;
                     const uint32_t want = left < 64u ? left : 64u;
-                    const uint32_t granted = hand_out(want, [&](uint32_t first, uint32_t n, uint32_t pix, uint32_t entry, uint32_t s0) {
+                    const uint32_t granted = hand_out(want, [&](uint32_t first, uint32_t n, uint32_t, uint32_t col, uint32_t row, uint32_t entry, uint32_t s0) {
                         if (lane - first < n) {  // (unsigned: first <= lane < first + n)
-                            gen_pix = pix;
+                            gen_col = col;
+                            gen_row = row;
                             gen_s = s0 + (lane - first);
                         }
 #pragma unroll
@@ -2797,9 +2812,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     float4* rec = scratch4;  // [64] {o, d.x} then [64] {d.y, d.z, rng, -}
                     if (lane < granted) {
                         Path np;
-                        const uint32_t lr = pixel_row(a, gen_pix), i = gen_pix - lr * a.width;
-                        const uint32_t j = tile_global_row(a, lr);
-                        camera_path(a, i, j, a.sample_offset + gen_s, np);
+                        camera_path(a, gen_col, gen_row, a.sample_offset + gen_s, np);
                         rec[lane] = make_float4(np.o.x, np.o.y, np.o.z, np.du.x);
                         rec[64u + lane] = make_float4(np.du.y, np.du.z, __uint_as_float(np.rng.state), 0.0f);
                     }
@@ -2828,11 +2841,12 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 Slot& q = sl[r];
                 const unsigned long long mask = r == 0 ? idle0 : idle1;
                 const uint32_t rank = lane_rank(mask);
-                uint32_t my_s = 0u, my_pix = 0u;
+                uint32_t my_s = 0u, my_col = 0u, my_row = 0u;
                 bool got_sample = false;
-                hand_out(static_cast<uint32_t>(__popcll(mask)), [&](uint32_t first, uint32_t n, uint32_t pix, uint32_t entry, uint32_t s0) {
+                hand_out(static_cast<uint32_t>(__popcll(mask)), [&](uint32_t first, uint32_t n, uint32_t, uint32_t col, uint32_t row, uint32_t entry, uint32_t s0) {
                     if (!q.active && rank - first < n) {
-                        my_pix = pix;
+                        my_col = col;
+                        my_row = row;
                         q.meta = meta_of(entry, cur_line);  // (depth 0)
                         my_s = s0 + (rank - first);
                         got_sample = true;
@@ -2840,9 +2854,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     return true;
                 });
                 if (got_sample) {  // start the sample
-                    const uint32_t lr = pixel_row(a, my_pix), i = my_pix - lr * a.width;
-                    const uint32_t j = tile_global_row(a, lr);
-                    camera_path(a, i, j, a.sample_offset + my_s, q.p);
+                    camera_path(a, my_col, my_row, a.sample_offset + my_s, q.p);
                     q.active = true;
                     ++n_paths;
                 }
@@ -3303,7 +3315,7 @@ int cone_selftest_host(const RtCamera& cam, uint32_t width, uint32_t height, uin
     a.crmax2 = range_rmax * range_rmax;
     PersistArgs g{};
     const bool cull = cone_setup(a, g);
-    const ConeAxis c = cull ? cone_of_span(a, g, pix_lo, pix_hi) : ConeAxis{};
+    const ConeAxis c = cull ? cone_of_span(a, g, pix_lo % width, pix_lo % width + (pix_hi - pix_lo), pix_lo / width) : ConeAxis{};
     for (uint32_t i = 0; i < n_spheres; ++i) {
         const float4 s = make_float4(spheres[i].cx, spheres[i].cy, spheres[i].cz, spheres[i].radius * spheres[i].radius);
         sphere_reach[i] = !cull || cone_reaches_sphere(a, g, c, s) ? 1u : 0u;
