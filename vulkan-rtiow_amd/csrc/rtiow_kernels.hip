@@ -982,14 +982,20 @@ DI void examine_keyed(const float4* slots, const uint32_t* idx_map, uint32_t slo
 DI void examine_cluster(const float4* slots, const uint32_t* idx_map, uint32_t base, uint32_t lane, const float ox,
                         const float oy, const float oz, const float dx, const float dy, const float dz,
                         unsigned long long& key) {
+    static_assert(kClusterSize == 16u && kClusterStride == 16u, "the member order below is an XOR on four bits of a cluster's first slot");
     uint32_t mm = 0u;
+    // Member step k of a lane reads slot (base + rot) ^ k, rot = lane % 16: for every k the sixteen lanes of an LDS access group touch
+    // sixteen different bank quads whatever clusters they are on, as with the rotation (k + rot) % 16 of rounds 1-3 -- but that one made
+    // sixteen lane constants, which the compiler kept in sixteen registers all kernel long; this one is one XOR with an immediate on
+    // the item's own number (`base` is a multiple of 16: the large spheres' slots are padded to whole clusters).
+    const uint32_t first = base + (lane & (kClusterSize - 1u));
     // four members per step, their reads issued together (left to itself the compiler keeps two reads in flight and
     // waits for each after eleven instructions; an LDS read with per-lane addresses takes longer than that)
 #pragma unroll
     for (uint32_t k0 = 0; k0 < kClusterSize; k0 += 4u) {
         float4 s4[4];
 #pragma unroll
-        for (uint32_t u = 0; u < 4u; ++u) s4[u] = slots[base + ((k0 + u + lane) & (kClusterSize - 1u))];
+        for (uint32_t u = 0; u < 4u; ++u) s4[u] = slots[first ^ (k0 + u)];
 #pragma unroll
         for (uint32_t u = 0; u < 4u; ++u) {
             const float4 s = s4[u];
@@ -1004,7 +1010,7 @@ DI void examine_cluster(const float4* slots, const uint32_t* idx_map, uint32_t b
     while (cand) {
         const uint32_t k = static_cast<uint32_t>(__builtin_clz(cand)) - (32u - kClusterSize);
         cand &= ~((1u << (kClusterSize - 1u)) >> k);
-        examine_keyed(slots, idx_map, base + ((k + lane) & (kClusterSize - 1u)), ox, oy, oz, dx, dy, dz, key);
+        examine_keyed(slots, idx_map, first ^ k, ox, oy, oz, dx, dy, dz, key);
     }
 }
 
@@ -1543,7 +1549,7 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
                         const uint32_t first = (s0 + (item >> 7)) * kSuperSize;
 #pragma unroll
                         for (uint32_t j = 0; j < kSuperSize; ++j) {
-                            const uint32_t k = (j + lane) & (kSuperSize - 1u);  // lane-rotated: spreads the LDS banks
+                            const uint32_t k = (j ^ lane) & (kSuperSize - 1u);  // lane-permuted (an XOR: see examine_cluster): spreads the LDS banks
                             float4 b = bounds[first + k];
                             b.z += fr[6];  // (0 for a ray within the range: the box as stored)
                             b.w += fr[6];
@@ -1568,7 +1574,7 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
                         const uint32_t first = (s0 + (item >> 7)) * kSuperSize;
 #pragma unroll
                         for (uint32_t j = 0; j < kSuperSize; ++j) {
-                            const uint32_t k = (j + lane) & (kSuperSize - 1u);  // lane-rotated: spreads the LDS banks
+                            const uint32_t k = (j ^ lane) & (kSuperSize - 1u);  // lane-permuted (an XOR: see examine_cluster): spreads the LDS banks
                             const float4 mid = bounds[2u * (first + k)];
                             float4 half = bounds[2u * (first + k) + 1u];
                             half.x += fr[6];  // (0 for a ray within the range: the box as stored)
