@@ -168,6 +168,16 @@ def cold_and_moving_frames(V, torch, dev, device_id, sph, mat, cam, prm, w, h, t
         res["first_frame_vs_timed_frame"] = "identical" if bool(torch.equal(cold, timed_frame.to(dev))) else "DIFFERS"
         fresh.render_device(cam, prm, cold.data_ptr(), w * 4, stream.cuda_stream)
         res["second_frame_ms"] = fresh.stats().kernel_ms
+    # what one frame costs the HOST: the rtRender call itself (ctypes, three event records, the launch), returning before the GPU is done
+    calls = []
+    for k in range(48):
+        t0 = time.perf_counter()
+        warm_ctx.render_device(cam, prm, scratch.data_ptr(), w * 4, stream.cuda_stream)
+        calls.append(time.perf_counter() - t0)
+        if k % 8 == 7:
+            torch.cuda.synchronize()
+    calls.sort()
+    res["host_enqueue_us_per_frame"] = calls[len(calls) // 2] * 1e6
     n = 16
     r0 = math.hypot(13.0, 3.0)
     cams = [V.make_camera((r0 * math.cos(a), 2.0, r0 * math.sin(a)), (0, 0, 0), (0, 1, 0), 20.0, w / h, 0.1, 10.0)
@@ -185,6 +195,14 @@ def cold_and_moving_frames(V, torch, dev, device_id, sph, mat, cam, prm, w, h, t
     loop([cam] * 4)
     res["static_camera_same_loop_ms_per_step"] = loop([cam] * n)
     res["moving_camera_ms_per_step"] = loop(cams)
+    bad = 0  # every orbit frame against a single-shot render of the same view by a fresh context
+    with V.Context(device_id) as fresh:
+        fresh.set_scene(sph, mat)
+        for k, c in enumerate(cams):
+            fresh.render_device(c, prm, scratch.data_ptr(), w * 4, stream.cuda_stream)
+            torch.cuda.synchronize()
+            bad += 0 if bool(torch.equal(scratch, bufs[k])) else 1
+    res["moving_camera_frames_vs_single_shot"] = "identical" if bad == 0 else f"{bad} of {n} DIFFER"
     # ... the orbit's views are other frames than the timed one (more of the glass ball, other path lengths): what moving costs is
     # read against the SAME sixteen views, each standing still until its own chunk order is there
     settled = 0.0
@@ -194,14 +212,6 @@ def cold_and_moving_frames(V, torch, dev, device_id, sph, mat, cam, prm, w, h, t
     res["moving_camera_views_standing_still_ms_per_step"] = settled / n
     res["moving_camera_penalty"] = res["moving_camera_ms_per_step"] / (settled / n) - 1.0
     res["moving_camera"] = f"{n} frames of an orbit around the look-at point, 3.75 degrees a frame, a new RtCamera every frame"
-    bad = 0
-    with V.Context(device_id) as fresh:
-        fresh.set_scene(sph, mat)
-        for k, c in enumerate(cams):
-            fresh.render_device(c, prm, scratch.data_ptr(), w * 4, stream.cuda_stream)
-            torch.cuda.synchronize()
-            bad += 0 if bool(torch.equal(scratch, bufs[k])) else 1
-    res["moving_camera_frames_vs_single_shot"] = "identical" if bad == 0 else f"{bad} of {n} DIFFER"
     return res
 
 

@@ -442,6 +442,7 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
             ++ctx->order_frames;
             a.chunk_cost = collect ? ctx->d_chunk_cost : nullptr;
             a.chunk_order = ctx->order_valid ? ctx->d_chunk_order : nullptr;
+            a.order_stale = moved ? 1u : 0u;
         }
         RT_HIP(ctx, rtiow::launch_path(a, kernel, prm->chunk_spp, ctx->num_cus, stream, &ctx->last_kernel));
         RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream));

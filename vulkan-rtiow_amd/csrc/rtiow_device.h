@@ -131,6 +131,7 @@ struct PathArgs {
     // the long paths of glass-heavy pixels start early and the frame ends on cheap ones.
     const uint32_t* chunk_order;
     unsigned long long* chunk_cost;  // null: not collected
+    uint32_t order_stale;            // (host side only) chunk_order was made from another view: the camera has moved since
 };
 
 struct ChArgs {

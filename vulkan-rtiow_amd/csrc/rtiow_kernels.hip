@@ -734,6 +734,10 @@ constexpr uint32_t kPoolWork = RTIOW_POOL_WORK;
 #ifndef RTIOW_LONG_WEIGHT
 #define RTIOW_LONG_WEIGHT 128
 #endif
+#ifndef RTIOW_COST_SAMPLE
+#define RTIOW_COST_SAMPLE 4  // of the pixels handed out one by one, every n-th reports its cost for its neighbours too (a power of two)
+#endif
+constexpr uint32_t kCostSample = RTIOW_COST_SAMPLE;
 constexpr uint32_t kLongFrom = RTIOW_LONG_FROM, kLongWeight = RTIOW_LONG_WEIGHT;  // cost of a path of more segments than kLongFrom, for the chunk order
 #ifndef RTIOW_FAR_LOCKSTEP
 #define RTIOW_FAR_LOCKSTEP 1  // (-DRTIOW_FAR_LOCKSTEP=0: A/B only -- a ray from outside the boxes' range takes every cluster of a one-level scene)
@@ -2475,8 +2479,8 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     const unsigned long long cost = (before >> 32) + segs;
                     if (cost >= static_cast<unsigned long long>(a.spp) * kLongFrom + kLongFrom * kLongWeight)  // (one long path at least)
                         atomicAdd(a.chunk_cost + done_pix / kChunkPix, cost);
-                    else if ((done_pix & 3u) == 0u)
-                        atomicAdd(a.chunk_cost + done_pix / kChunkPix, 4ull * cost);
+                    else if ((done_pix & (kCostSample - 1u)) == 0u)
+                        atomicAdd(a.chunk_cost + done_pix / kChunkPix, static_cast<unsigned long long>(kCostSample) * cost);
                 }
             }
         }
@@ -3465,7 +3469,12 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
         // traffic: see kPoolWork).  Where it is small -- a quarter or an eighth of the cover frame, a 16-spp frame, 300 x 200 x 10 spp
         // with its 146 samples per wave -- pools stay as they were: doubled they took one eighth of the cover frame from 1.02 to 1.09 ms,
         // capped at an eighth the 300 x 200 frame from 0.28 to 0.36 (profiles/r04_pool_rule.txt).
-        const bool large_share = static_cast<unsigned long long>(g.total_pix) * a.spp / g.total_waves >= 8192ull;
+#ifndef RTIOW_STALE_SMALL_POOLS
+#define RTIOW_STALE_SMALL_POOLS 1  // (-DRTIOW_STALE_SMALL_POOLS=0: A/B only)
+#endif
+        // (... and only in an order made for THIS view: a large pool of a chunk the last view took for sky is one wave's time late in the frame)
+        const bool large_share = static_cast<unsigned long long>(g.total_pix) * a.spp / g.total_waves >= 8192ull &&
+                                 !(RTIOW_STALE_SMALL_POOLS && a.order_stale != 0u);
         if (large_share && !debug_knob("RTIOW_DEBUG_POOL_PIX")) {
             g.pool_pix = 2u * pool_samples / a.spp;
             g.pool_pix = g.pool_pix < 1u ? 1u : (g.pool_pix > 256u ? 256u : g.pool_pix);
@@ -3498,7 +3507,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
         g.fine_pix = 128u / a.spp < 1u ? 1u : 128u / a.spp;  // (a 1-spp frame: 128 pixels -- more than its pools hold, i.e. no fine dealing)
         // (small frames only -- fewer than 48 pixels per wave, one eighth of the cover frame has 29: on larger ones no single pool
         // is the frame's time, and every fetch is two dependent atomics and ~40 bytes of fabric traffic)
-        const bool small_frame = g.total_pix / g.total_waves < 48u;
+        const bool small_frame = g.total_pix / g.total_waves < 48u || (RTIOW_STALE_SMALL_POOLS && a.order_stale != 0u);
         g.fine_until = (g.chunk_until == ~0u && a.chunk_order != nullptr && div != 0u && g.pool_pix > g.fine_pix && small_frame) ? g.total_pix / 8u / div : 0u;
     }
     hipLaunchKernelGGL(kernel_fn, dim3(static_cast<uint32_t>(grid)), dim3(threads), lds, stream, a, g);
