@@ -735,7 +735,12 @@ constexpr uint32_t kPoolWork = RTIOW_POOL_WORK;
 #define RTIOW_LONG_WEIGHT 128
 #endif
 #ifndef RTIOW_COST_SAMPLE
-#define RTIOW_COST_SAMPLE 4  // of the pixels handed out one by one, every n-th reports its cost for its neighbours too (a power of two)
+#define RTIOW_COST_SAMPLE 16  // of the pixels handed out one by one, every n-th reports its cost for its neighbours too (a power of two).
+                              // (Rounds 2-3: every fourth.  A report is a memory-side atomic, ~40 bytes of fabric traffic; since the cover frame hands
+                              // out no whole chunks -- section "Stores" -- a reporting frame made 240 000 of them, 9.6 MB.  Two reports per 32-pixel
+                              // chunk order the next frame as well as eight: frames standing still 6.196 / 6.190 / 6.200 ms with every 4th / 8th / 16th,
+                              // an orbit +7.4 / +7.8 / +6.5 % -- profiles/r04_moving_camera.txt -- and a path of more than kLongFrom segments reports
+                              // for itself whatever its pixel.)
 #endif
 constexpr uint32_t kCostSample = RTIOW_COST_SAMPLE;
 constexpr uint32_t kLongFrom = RTIOW_LONG_FROM, kLongWeight = RTIOW_LONG_WEIGHT;  // cost of a path of more segments than kLongFrom, for the chunk order
