@@ -2,7 +2,7 @@
 metadata notes at the end of each .s file).  usage: asm_report.py [file.s ...]"""
 import os, re, sys
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vulkan-rtiow_amd", "csrc")
-files = sys.argv[1:] or [os.path.join(root, "rtiow_kernels.s"), os.path.join(root, "rtiow_kernels_small.s")]
+files = sys.argv[1:] or [os.path.join(root, n) for n in ("rtiow_kernels.s", "rtiow_kernels_small.s", "rtiow_kernels_large.s")]
 keys = (".vgpr_count", ".vgpr_spill_count", ".sgpr_count", ".sgpr_spill_count", ".private_segment_fixed_size", ".max_flat_workgroup_size")
 for f in files:
     text = open(f).read()

@@ -31,6 +31,13 @@
 #include "rtiow_device.h"
 #include "rtiow_rng.h"
 
+// This file is compiled three times (Makefile): whole, and twice for one family of the clustered persistent kernels each, with a
+// scheduler (and a register budget) of its own -- -DRTIOW_TU_SMALL_CLUSTERED: the small-scene variants, -DRTIOW_TU_LARGE_CLUSTERED:
+// the large-scene ones.  Those two passes compile the shared device code and their kernels only (see the end of the file).
+#if defined(RTIOW_TU_SMALL_CLUSTERED) || defined(RTIOW_TU_LARGE_CLUSTERED)
+#define RTIOW_TU_PART
+#endif
+
 namespace rtiow {
 namespace {
 
@@ -186,7 +193,7 @@ DI float lean_div(float a, float b) {
 DI float psqrt(float x) { return RTIOW_LEAN_PATH ? lean_sqrt(x) : __builtin_sqrtf(x); }
 DI float pdiv(float a, float b) { return RTIOW_LEAN_PATH ? lean_div(a, b) : a / b; }
 
-#ifndef RTIOW_TU_SMALL_CLUSTERED
+#ifndef RTIOW_TU_PART
 // ch_kernel_tiles: the shaders as the reference dispatches them -- 16x16 workgroup as raytrace06.comp:2, one lane per
 // pixel; ceil-div grid with a bounds check (fixes the fixed 64x64 / floor-div dispatches of main.cpp:321 and RTCHAP05
 // main.cpp:306).  One packed 32-bit store per lane: a wave writes four 64-byte row segments.  Kept for degenerate images
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(256) void ch_kernel_rows(ChArgs a) {
     }
 }
 
-#endif  // RTIOW_TU_SMALL_CLUSTERED
+#endif  // RTIOW_TU_PART
 
 // ============================================================================
 // PATH mode building blocks (BUILD-SPEC: SURVEY.md section 9)
@@ -592,7 +599,7 @@ DI int closest_hit_simple(const float4* lds, uint32_t n, const Path& p, float& b
     return best_i;
 }
 
-#ifndef RTIOW_TU_SMALL_CLUSTERED
+#ifndef RTIOW_TU_PART
 // ============================================================================
 // PATH v1: one lane per pixel (reference form; kept as a cross-check and ablation)
 // ============================================================================
@@ -643,7 +650,7 @@ __global__ __launch_bounds__(256) void path_pixel_kernel(PathArgs a) {
     }
 }
 
-#endif  // RTIOW_TU_SMALL_CLUSTERED
+#endif  // RTIOW_TU_PART
 
 // ============================================================================
 // PATH v2: persistent waves, per-pixel LDS accumulators, ballot refill, candidate bitmasks
@@ -802,6 +809,7 @@ struct PersistArgs {
 };
 using PersistentKernelFn = void (*)(PathArgs, PersistArgs);
 PersistentKernelFn small_clustered_kernel(bool flat);  // path_persistent_kernel<true, true, flat>, from the second compilation of this file
+PersistentKernelFn large_clustered_kernel(bool flat);  // path_persistent_kernel<false, true, flat>, from the third
 namespace {
 
 DI void examine_candidate(const float4* lds, uint32_t j, uint32_t n, const Path& p, float& best,
@@ -2125,7 +2133,7 @@ HDI bool cone_reaches_sphere(const PathArgs& a, const PersistArgs& g, const Cone
 }
 
 // exact test of the sphere in slot `slot` (wave-uniform: LDS broadcast) for the lane's own ray, branch-free
-DI void exact_keyed_lockstep(const float4* slots, const uint32_t* idx_map, uint32_t slot, const Path& p,
+[[maybe_unused]] DI void exact_keyed_lockstep(const float4* slots, const uint32_t* idx_map, uint32_t slot, const Path& p,
                              unsigned long long& key) {
     const float4 s = slots[slot];
     const uint32_t lo = (idx_map[slot] << 16) | slot;
@@ -3118,7 +3126,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
 #endif
 }
 
-#ifndef RTIOW_TU_SMALL_CLUSTERED
+#ifndef RTIOW_TU_PART
 // ============================================================================
 // arithmetic conformance probe (tests/test_gpu_parity.py::test_arith_bit_exact)
 // ============================================================================
@@ -3230,7 +3238,7 @@ __global__ __launch_bounds__(1024) void order_chunks_kernel(unsigned long long* 
     }
 }
 
-#endif  // RTIOW_TU_SMALL_CLUSTERED
+#endif  // RTIOW_TU_PART
 }  // namespace
 
 // The small-scene clustered kernels -- the default kernel of the headline frame -- are compiled in a second pass over this
@@ -3241,9 +3249,16 @@ __global__ __launch_bounds__(1024) void order_chunks_kernel(unsigned long long* 
 // then finds two groups of 512 threads per CU: cover frame 7.95 -> 7.19 ms, one eighth of it 1.33 -> 1.26 (interleaved A/B,
 // tools/ab_bench.py; iterative-minreg at three waves: 8.48).  Round 4: with Slot's bookkeeping in one register and one base for the per-wave LDS areas, none.  The large-scene variants spill 115 registers at 128 and have no LDS for sixteen
 // waves' buffers, the flat-list kernels (95 registers) gain nothing: they stay with the default scheduler.
-#ifdef RTIOW_TU_SMALL_CLUSTERED
+// Round 4: the large-scene variants get a pass of their own too (-DRTIOW_TU_LARGE_CLUSTERED, rtiow_kernels_large.o) under iterative-ilp: at 148
+// registers (three waves per SIMD allow 168) it spills nothing and the 4099-sphere scene renders 1.8 % faster than under the default
+// scheduler (max-ilp: +1 %, iterative-minreg: +5 %; profiles/r04_scheduler_ab.txt); the flat-list kernels keep the default one.
+#if defined(RTIOW_TU_SMALL_CLUSTERED)
 PersistentKernelFn small_clustered_kernel(bool flat) {
     return flat ? path_persistent_kernel<true, true, true> : path_persistent_kernel<true, true, false>;
+}
+#elif defined(RTIOW_TU_LARGE_CLUSTERED)
+PersistentKernelFn large_clustered_kernel(bool flat) {
+    return flat ? path_persistent_kernel<false, true, true> : path_persistent_kernel<false, true, false>;
 }
 #else
 
@@ -3404,7 +3419,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // make no more paths than there are idle slots, and the records sit in the two-level work-list area alone
     auto wave_bytes = [&](uint32_t keep) { return kWaveAccBytes + kWavePixBytes + kWaveLineBytes + (accel ? item_bytes + keep * kPassRecBytes : 0u); };
     void (*kernel_fn)(PathArgs, PersistArgs) =
-        accel ? (shade_lds ? small_clustered_kernel(flat) : (flat ? path_persistent_kernel<false, true, true> : path_persistent_kernel<false, true, false>))
+        accel ? (shade_lds ? small_clustered_kernel(flat) : large_clustered_kernel(flat))
               : (shade_lds ? path_persistent_kernel<true, false> : path_persistent_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsPerCu));
@@ -3526,6 +3541,6 @@ hipError_t launch_arith(uint32_t op, const float* a, const float* b, const float
     return hipGetLastError();
 }
 
-#endif  // RTIOW_TU_SMALL_CLUSTERED
+#endif  // RTIOW_TU_SMALL_CLUSTERED / RTIOW_TU_LARGE_CLUSTERED
 
 }  // namespace rtiow
