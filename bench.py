@@ -163,11 +163,21 @@ def cold_and_moving_frames(V, torch, dev, device_id, sph, mat, cam, prm, w, h, t
         res["scene_build_ms"] = ss.scene_build_ms
         res["cluster_builds"] = int(ss.cluster_builds)
         cold = torch.zeros((h, w), dtype=torch.int32, device=dev)
-        fresh.render_device(cam, prm, cold.data_ptr(), w * 4, stream.cuda_stream)
-        res["first_frame_ms"] = fresh.stats().kernel_ms
-        res["first_frame_vs_timed_frame"] = "identical" if bool(torch.equal(cold, timed_frame.to(dev))) else "DIFFERS"
-        fresh.render_device(cam, prm, cold.data_ptr(), w * 4, stream.cuda_stream)
-        res["second_frame_ms"] = fresh.stats().kernel_ms
+        again = torch.zeros((h, w), dtype=torch.int32, device=dev)
+        # the first two frames back to back on one stream, timed by events on that stream (an idle gap between them -- a host-side
+        # comparison, say -- lets the clock drop and costs the next frame 5-10 % whatever its chunk order: tools/first_frames.py)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        with torch.cuda.stream(stream):
+            ev[0].record()
+            fresh.render_device(cam, prm, cold.data_ptr(), w * 4, stream.cuda_stream)
+            ev[1].record()
+            fresh.render_device(cam, prm, again.data_ptr(), w * 4, stream.cuda_stream)
+            ev[2].record()
+        torch.cuda.synchronize()
+        res["first_frame_ms"] = ev[0].elapsed_time(ev[1])
+        res["second_frame_ms"] = ev[1].elapsed_time(ev[2])
+        same = bool(torch.equal(cold, timed_frame.to(dev))) and bool(torch.equal(again, cold))
+        res["first_frame_vs_timed_frame"] = "identical" if same else "DIFFERS"
     # what one frame costs the HOST: the rtRender call itself (ctypes, three event records, the launch), returning before the GPU is done
     calls = []
     for k in range(48):

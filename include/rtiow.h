@@ -219,7 +219,8 @@ int rtGetLastKernel(RtContext* ctx, uint32_t* kernel_out);
 
 /* Arithmetic conformance probe (diagnostic): evaluates one operation per
  * element on the GPU over host arrays — op 0 fma(a,b,c), 1 a/b, 2 sqrt(a),
- * 3 a*b, 4 a+b, 5 RNG draw, 6 fixed-point accumulate, 7 u64->float — so a CPU/GPU rounding difference can be pinned to
+ * 3 a*b, 4 a+b, 5 RNG draw, 6 fixed-point accumulate, 7 u64->float, 8 / 9 the kernels' own shortened square root / quotient
+ * (to be compared with 2 / 1 on operands inside their stated ranges) — so a CPU/GPU rounding difference can be pinned to
  * a single operation.  No reference counterpart. */
 int rtSelfTestArith(RtContext* ctx, uint32_t op, const float* a, const float* b, const float* c,
                     float* out, uint32_t n);

@@ -53,6 +53,47 @@ def test_arith_bit_exact(gpu_ctx, oracle, op, name):
     assert ok.all(), (name, int((~ok).sum()), a[~ok][:4], b[~ok][:4], got[~ok][:4], want[~ok][:4])
 
 
+def test_lean_square_root_and_quotient_equal_the_correctly_rounded_ones(gpu_ctx, oracle):
+    """The kernels take most of their square roots and the quotient of unit3 by the cores of hipcc's correctly rounded expansions,
+    without the range handling around them (rtiow_kernels.hip: lean_sqrt, lean_div).  On operands inside the stated
+    preconditions -- x == 0 or x >= 2^-96 (any magnitude above), NaN, +inf, negatives; normal a and b less than 96 binades apart with a
+    normal quotient, a == 0 -- they are the oracle's sqrtf and / bit for bit: 2^18 random operands each, plus the edges."""
+    rng = np.random.default_rng(404)
+    n = 1 << 18
+    # square root: exponents from 2^-96 up to the top, every mantissa pattern
+    e = rng.integers(127 - 96, 255, n, dtype=np.uint64)
+    m = rng.integers(0, 1 << 23, n, dtype=np.uint64)
+    x = ((e << 23) | m).astype(np.uint32).view(np.float32).copy()
+    edges = np.array([0.0, -0.0, 2.0 ** -96, np.float32(2.0 ** -96) * np.float32(1.0000001), 1.0, 4.0, 2.0, 3.4028235e38, np.inf, np.nan,
+                      -1.0, -np.inf, 1e-20, 0.25, 0.99999994, 1.0000001], np.float32)
+    x[:len(edges)] = edges
+    dummy = np.ones(n, np.float32)
+    got = gpu_ctx.selftest_arith(8, x, dummy, dummy)
+    want = oracle.arith(2, x, dummy, dummy)
+    ok = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert ok.all(), ("lean_sqrt", int((~ok).sum()), x[~ok][:4], got[~ok][:4], want[~ok][:4])
+    # quotient: a in [2^-40, 2^40] with either sign (and 0), b in [2^-40, 2^40]: exponents at most 80 apart, the quotient normal
+    def pick(lo, hi):
+        ee = rng.integers(127 + lo, 127 + hi, n, dtype=np.uint64)
+        mm = rng.integers(0, 1 << 23, n, dtype=np.uint64)
+        sg = rng.integers(0, 2, n, dtype=np.uint64)
+        return ((sg << 31) | (ee << 23) | mm).astype(np.uint32).view(np.float32).copy()
+    a, b = pick(-40, 40), pick(-40, 40)
+    a[:8] = np.array([0.0, 1.0, 1.0, 1.0, -1.0, 3.0, 1.0, 2.0 ** 40], np.float32)
+    b[:8] = np.array([3.0, 3.0, 1e-8, 4.0, 7.0, 1.0, 0.99999994, 2.0 ** -40], np.float32)
+    got = gpu_ctx.selftest_arith(9, a, b, dummy)
+    want = oracle.arith(1, a, b, dummy)
+    ok = got.view(np.uint32) == want.view(np.uint32)
+    ok |= (got == 0.0) & (want == 0.0)  # (a zero dividend: the lean quotient is +0 where IEEE gives -0 for a negative divisor; no kernel site can tell)
+    assert ok.all(), ("lean_div", int((~ok).sum()), a[~ok][:4], b[~ok][:4], got[~ok][:4], want[~ok][:4])
+    # unit3_scattered's own use: 1 / sqrt(x) for x in [1e-16, 16]
+    xs = (rng.random(n, dtype=np.float32) * np.float32(16.0)).astype(np.float32) + np.float32(1e-16)
+    r = gpu_ctx.selftest_arith(8, xs, dummy, dummy)
+    got = gpu_ctx.selftest_arith(9, dummy, r, dummy)
+    want = oracle.arith(1, dummy, oracle.arith(2, xs, dummy, dummy), dummy)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 # ---- the reference's own kernels -------------------------------------------------
 @pytest.mark.parametrize("mode", [V.RT_MODE_CH05, V.RT_MODE_CH06])
 @pytest.mark.parametrize("w,h", [(800, 608), (400, 225), (1024, 1024), (33, 17), (16, 16), (1, 1), (1200, 800)])

@@ -722,12 +722,12 @@ int rtGetLastKernel(RtContext* ctx, uint32_t* kernel_out) {
 }
 
 // Arithmetic conformance probe: runs op over host arrays on the GPU
-// (0 fma, 1 div, 2 sqrt, 3 mul, 4 add, 5 RNG draw, 6 fixed-point accumulate, 7 u64->float).  Used by the parity tests to
+// (0 fma, 1 div, 2 sqrt, 3 mul, 4 add, 5 RNG draw, 6 fixed-point accumulate, 7 u64->float, 8 / 9 the kernels' lean square root / quotient).  Used by the parity tests to
 // localise any CPU/GPU rounding difference to a single operation.
 int rtSelfTestArith(RtContext* ctx, uint32_t op, const float* a, const float* b, const float* c,
                     float* out, uint32_t n) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rtSelfTestArith: ctx is null");
-    if (!a || !b || !c || !out || n == 0 || op > 7)
+    if (!a || !b || !c || !out || n == 0 || op > 9)
         return fail(ctx, RT_ERR_INVALID, "rtSelfTestArith: bad arguments");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     float* d = nullptr;

@@ -3151,6 +3151,8 @@ __global__ void arith_kernel(uint32_t op, const float* a, const float* b, const 
             r = static_cast<float>((static_cast<unsigned long long>(__float_as_uint(a[i])) << 32) |
                                    __float_as_uint(b[i]));
             break;
+        case 8: r = lean_sqrt(a[i]); break;      // the PATH and CH kernels' lean forms themselves (psqrt / pdiv; ch_pixel<LEAN>):
+        case 9: r = lean_div(a[i], b[i]); break; // against sqrtf and / on operands inside their preconditions
         default: break;
     }
     out[i] = r;
