@@ -331,7 +331,9 @@ def test_clustered_kernels_keep_their_waves_per_simd():
             # and at 28 -- 48.5 MB of scratch write-back per cover frame -- in round 3)
             assert vgpr[k] <= 128 and scratch[k] <= (8 if flat else 32), (k, vgpr[k], scratch[k])
         elif clustered:
-            assert vgpr[k] <= 168 and scratch[k] == 0, (k, vgpr[k], scratch[k])
+            # (round 4: a compilation pass of their own under iterative-ilp, which uses all 168 registers three waves allow and may
+            # put a few wave-uniform values into scratch: 20 bytes for the flat-axis variant)
+            assert vgpr[k] <= 168 and scratch[k] <= 32, (k, vgpr[k], scratch[k])
         else:
             assert vgpr[k] <= 96 and scratch[k] == 0, (k, vgpr[k], scratch[k])
 

@@ -295,8 +295,8 @@ static int render_common(RtContext* ctx, bool is_ch, const RtUbo5* ubo, const Rt
     if (tcount > 1 && prm->tile_rank >= tcount)
         return fail(ctx, RT_ERR_INVALID, "rtRender: tile_rank >= tile_count");
     const uint32_t rows = rtTileRowCount(H, rblock, prm->tile_rank, tcount);
-    if (!is_ch && uint64_t(rows) * W > 0x7FFFFFFFull)  // the pixel queues count in 32 bits
-        return fail(ctx, RT_ERR_INVALID, "rtRender: more than 2^31 pixels in one tile");
+    if (!is_ch && uint64_t(rows) * W >= (1ull << 29))  // (the kernels keep a pixel's number in 29 bits: rtiow_kernels.hip, kPixLineShift)
+        return fail(ctx, RT_ERR_INVALID, "rtRender: more than 2^29 pixels in one tile");
 
     RT_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t stream = stream_handle ? static_cast<hipStream_t>(stream_handle) : ctx->stream;

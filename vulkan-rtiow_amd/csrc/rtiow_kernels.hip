@@ -775,10 +775,15 @@ constexpr uint32_t kSparseMaxAccel = RTIOW_SPARSE_MAX_ACCEL;  // the same for th
 // accumulator entry, written when the pixel is opened).  Rounds 1-3 carried pixel, entry, line and depth in a register each, eight
 // per lane -- the first place to look when the four-waves variant spilled 28.
 constexpr uint32_t kMetaLineShift = 10, kMetaDepthShift = 13;
+constexpr uint32_t kPixLineShift = 29;  // lds_pix: the entry's pixel (rtRender caps a tile at 2^29 pixels) | its line buffer + 1 << 29
+#ifndef RTIOW_RESOLVE_BATCH
+#define RTIOW_RESOLVE_BATCH 16  // (4 / 8 / 16: cover frame 6.18 / 6.17 / 6.14 ms against 6.21 resolving at once; 64 entries per wave)
+#endif
+constexpr uint32_t kResolveBatch = RTIOW_RESOLVE_BATCH;  // done entries a wave lets gather before it resolves them (resolve_done)
 static_assert(kMaxPathDepth == (1u << (32u - kMetaDepthShift)) - 1u, "rtRender's cap on max_depth is the depth field of Slot::meta");
 DI uint32_t meta_of(uint32_t entry, uint32_t line) { return entry | (line << kMetaLineShift); }
 DI uint32_t meta_entry(uint32_t m) { return m & ((1u << kMetaLineShift) - 1u); }
-DI uint32_t meta_line(uint32_t m) { return (m >> kMetaLineShift) & 7u; }
+[[maybe_unused]] DI uint32_t meta_line(uint32_t m) { return (m >> kMetaLineShift) & 7u; }
 DI uint32_t meta_depth(uint32_t m) { return m >> kMetaDepthShift; }
 struct Slot {
     Path p;
@@ -2381,6 +2386,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     uint32_t cur_seq = ~0u, cur_chunk = 0u;  // position in the chunk sequence the wave is in, and the chunk there
     uint32_t cur_s = a.spp;                  // its next sample; == spp: no pixel open
     unsigned long long free_entries = ~0ull; // accumulator entries not in use
+    unsigned long long done_entries = 0ull;  // ... entries whose pixel has all its samples and waits to be resolved (resolve_done)
     uint32_t free_lines = (1u << kLineBufs) - 1u;  // line buffers not in use
     uint32_t whole_done = 0u;                // bit q: the whole-chunk part of queue q is known to be handed out
     uint32_t rest_done = 0u;                 // ... and the rest of it
@@ -2449,12 +2455,9 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 }
             }
         }
-        // A finished sample bumps its pixel's counter; the lane that completes the pixel
-        // resolves it.  All adds to the entry were issued by earlier LDS instructions of
-        // this wave (or serialised within this one), so the sums it reads are final.
+        // A finished sample bumps its pixel's counter; the sample that completes the pixel marks its accumulator entry as done
+        // (resolve_done below turns done entries into pixels of the frame, several at a time).
         bool completed = false;
-        bool line_full = false;  // this lane's pixel was the last of a line buffer
-        uint32_t done_pix = 0u;  // the pixel this lane's sample completed
         if (finished) {
 #ifdef RTIOW_DEBUG_TIMELINE
             if (tl_dry != 0ull && meta_depth(q.meta) + 1u > tl_deepest) tl_deepest = meta_depth(q.meta) + 1u;
@@ -2469,57 +2472,73 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             const uint32_t segs1 = meta_depth(q.meta) < 0xFFFEu ? meta_depth(q.meta) + 1u : 0xFFFFu;
             const uint32_t segs = segs1 > kLongFrom ? (segs1 * kLongWeight < 0xFFFFu ? segs1 * kLongWeight : 0xFFFFu) : segs1;
             const unsigned long long before = atomicAdd(acc + 3, 1ull | (static_cast<unsigned long long>(segs) << 32));
-            if (static_cast<uint32_t>(before) + 1u == a.spp) {
-                completed = true;
-                done_pix = lds_pix[meta_entry(q.meta)];  // (written when the pixel was opened: hand_out)
-                const uint32_t colour = close_pixel(a, done_pix, acc[0], acc[1], acc[2]);
-                const uint32_t line = meta_line(q.meta);
-                if (line == 0u) {
-                    const uint32_t lr = pixel_row(a, done_pix), i = done_pix - lr * a.width;
-                    a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = colour;
-                } else {  // a pixel of a chunk this wave renders alone: into the line buffer
-                    lds_line[(line - 1u) * kChunkPix + done_pix % kChunkPix] = colour;
-                    uint32_t* meta = lds_line_meta + kLineMetaWords * (line - 1u);
-                    atomicAdd(reinterpret_cast<unsigned long long*>(meta + 2), (before >> 32) + segs);  // the chunk's cost, in LDS
-                    const uint32_t done = atomicAdd(meta, 1u);
-                    line_full = done + 1u == meta[1];
-                }
-                // what this pixel cost, for the next frame's chunk order (a global atomic leaves the L2 as a 64-byte
-                // memory-side request: whole chunks sum theirs in LDS and report once, with the line)
-                // ... and of the pixels handed out one by one, every fourth speaks for its neighbours -- unless a long
-                // path ended in this one: those are what the order is for, and too rare to be sampled
-                if (a.chunk_cost != nullptr && line == 0u) {
-                    const unsigned long long cost = (before >> 32) + segs;
-                    if (cost >= static_cast<unsigned long long>(a.spp) * kLongFrom + kLongFrom * kLongWeight)  // (one long path at least)
-                        atomicAdd(a.chunk_cost + done_pix / kChunkPix, cost);
-                    else if ((done_pix & (kCostSample - 1u)) == 0u)
-                        atomicAdd(a.chunk_cost + done_pix / kChunkPix, static_cast<unsigned long long>(kCostSample) * cost);
-                }
-            }
+            completed = static_cast<uint32_t>(before) + 1u == a.spp;
         }
-        // Completed pixels (0-2 per iteration): their accumulator entries return to the wave; a pixel that filled
-        // its line buffer has the line stored -- up to 32 consecutive pixels, 128 bytes, the whole line of the
-        // frame in one store.  (A wave's LDS operations are performed in order: the colour written above is there.)
-        unsigned long long done_mask = __ballot(completed);
+        unsigned long long done_mask = __ballot(completed);  // (0-2 lanes per call at a hundred samples per pixel)
         while (done_mask != 0ull) {
             const int l = __builtin_ctzll(done_mask);
             done_mask &= done_mask - 1ull;
-            const uint32_t m = __builtin_amdgcn_readlane(q.meta, l);
-            free_entries |= 1ull << meta_entry(m);
-            if (__builtin_amdgcn_readlane(static_cast<uint32_t>(line_full), l) != 0u) {
-                const uint32_t line = meta_line(m) - 1u;
-                const uint32_t first = __builtin_amdgcn_readlane(done_pix, l) / kChunkPix * kChunkPix;
-                const uint32_t count = g.total_pix - first < kChunkPix ? g.total_pix - first : kChunkPix;
-                if (lane < count) {
-                    const uint32_t pix = first + lane;
-                    const uint32_t lr = pixel_row(a, pix), i = pix - lr * a.width;  // (a chunk may run over the end of a row)
-                    a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = lds_line[line * kChunkPix + lane];
-                }
-                if (a.chunk_cost != nullptr && lane == 0u)  // this wave rendered the whole chunk: a plain store
-                    a.chunk_cost[first / kChunkPix] = *reinterpret_cast<const unsigned long long*>(lds_line_meta + kLineMetaWords * line + 2u);
-                free_lines |= 1u << line;
+            done_entries |= 1ull << meta_entry(__builtin_amdgcn_readlane(q.meta, l));
+        }
+    };
+    // Done entries -> pixels of the frame: lane e takes entry e.  All adds to an entry were issued by earlier LDS instructions of this
+    // wave, so the sums are final; resolve, quantise and store are ~125 vector instructions, and rounds 1-3 ran them in the lane whose
+    // sample completed the pixel, at once -- one or two lanes of 64, in every fourth pass of the shade code: 3 % of the kernel's
+    // instructions for 1 / 64 of their worth.  Now the entries wait (the main loop calls this when kResolveBatch of them have
+    // gathered, hand_out when it runs out of entries, the wave when it is through) and go eight and more at a time.
+    auto resolve_done = [&]() {
+        if (done_entries == 0ull) return;
+        const bool mine = ((done_entries >> lane) & 1ull) != 0ull;
+        bool line_full = false;  // this lane's pixel was the last of a line buffer
+        uint32_t done_pix = 0u, my_line = 0u;
+        if (mine) {
+            unsigned long long* acc = lds_acc + lane * kAccWords;
+            const uint32_t where = lds_pix[lane];  // (written when the pixel was opened: hand_out)
+            done_pix = where & ((1u << kPixLineShift) - 1u);
+            my_line = where >> kPixLineShift;
+            const unsigned long long cost = acc[3] >> 32;  // what the pixel's samples cost (weighted segments: see shade_one)
+            const uint32_t colour = close_pixel(a, done_pix, acc[0], acc[1], acc[2]);
+            if (my_line == 0u) {
+                const uint32_t lr = pixel_row(a, done_pix), i = done_pix - lr * a.width;
+                a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = colour;
+            } else {  // a pixel of a chunk this wave renders alone: into the line buffer
+                lds_line[(my_line - 1u) * kChunkPix + done_pix % kChunkPix] = colour;
+                uint32_t* meta = lds_line_meta + kLineMetaWords * (my_line - 1u);
+                atomicAdd(reinterpret_cast<unsigned long long*>(meta + 2), cost);  // the chunk's cost, in LDS
+                const uint32_t done = atomicAdd(meta, 1u);
+                line_full = done + 1u == meta[1];
+            }
+            // what this pixel cost, for the next frame's chunk order (a global atomic leaves the L2 as a 64-byte
+            // memory-side request: whole chunks sum theirs in LDS and report once, with the line)
+            // ... and of the pixels handed out one by one, every kCostSample-th speaks for its neighbours -- unless a long
+            // path ended in this one: those are what the order is for, and too rare to be sampled
+            if (a.chunk_cost != nullptr && my_line == 0u) {
+                if (cost >= static_cast<unsigned long long>(a.spp) * kLongFrom + kLongFrom * kLongWeight)  // (one long path at least)
+                    atomicAdd(a.chunk_cost + done_pix / kChunkPix, cost);
+                else if ((done_pix & (kCostSample - 1u)) == 0u)
+                    atomicAdd(a.chunk_cost + done_pix / kChunkPix, static_cast<unsigned long long>(kCostSample) * cost);
             }
         }
+        // a pixel that filled its line buffer has the line stored -- up to 32 consecutive pixels, 128 bytes, the whole line of the
+        // frame in one store.  (A wave's LDS operations are performed in order: the colours written above are there.)
+        unsigned long long full = __ballot(line_full);
+        while (full != 0ull) {
+            const int l = __builtin_ctzll(full);
+            full &= full - 1ull;
+            const uint32_t line = __builtin_amdgcn_readlane(my_line, l) - 1u;
+            const uint32_t first = __builtin_amdgcn_readlane(done_pix, l) / kChunkPix * kChunkPix;
+            const uint32_t count = g.total_pix - first < kChunkPix ? g.total_pix - first : kChunkPix;
+            if (lane < count) {
+                const uint32_t pix = first + lane;
+                const uint32_t lr = pixel_row(a, pix), i = pix - lr * a.width;  // (a chunk may run over the end of a row)
+                a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = lds_line[line * kChunkPix + lane];
+            }
+            if (a.chunk_cost != nullptr && lane == 0u)  // this wave rendered the whole chunk: a plain store
+                a.chunk_cost[first / kChunkPix] = *reinterpret_cast<const unsigned long long*>(lds_line_meta + kLineMetaWords * line + 2u);
+            free_lines |= 1u << line;
+        }
+        free_entries |= done_entries;  // the entries return to the wave
+        done_entries = 0ull;
     };
     [[maybe_unused]] bool to_sparse_loop = false;  // the wave leaves the main loop for the sparse loop below
     for (;;) {
@@ -2647,6 +2666,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                         ++pool_next;
                         continue;
                     }
+                    if (free_entries == 0ull) resolve_done();  // (entries that only wait to be stored)
                     if (free_entries == 0ull) {  // 64 pixels in flight: wait for one to finish
 #ifdef RTIOW_DEBUG_TIMELINE
                         ++tl_starved;
@@ -2668,7 +2688,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     ++pool_next;
                     cur_s = 0u;
                     if (lane < kAccWords) lds_acc[cur_entry * kAccWords + lane] = 0ull;
-                    if (lane == kAccWords) lds_pix[cur_entry] = pix;
+                    if (lane == kAccWords) lds_pix[cur_entry] = pix | (cur_line << kPixLineShift);
                 }
                 const uint32_t n = want - served < a.spp - cur_s ? want - served : a.spp - cur_s;
                 if (!on_range(served, n, cur_pix, cur_col, cur_row, cur_entry, cur_s)) break;  // (the pixel stays open)
@@ -2968,6 +2988,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         }
 #pragma unroll
         for (int r = 0; r < kSlots; ++r) shade_one(sl[r], best[r], best_i[r], best_o[r], rec0[r], rec1[r]);
+        if (static_cast<uint32_t>(__popcll(done_entries)) >= kResolveBatch) resolve_done();
         DBG_ADD(dbg_t_refill, t1 - t0);
         DBG_ADD(dbg_t_trace, t2 - t1);
         DBG_ADD(dbg_t_shade, DBG_STAMP() - t2);
@@ -3014,6 +3035,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             }
         }
     }
+    resolve_done();  // the wave's last pixels
 
 #ifdef RTIOW_DEBUG_TIMELINE
     for (int off = 32; off > 0; off >>= 1) {
