@@ -619,3 +619,28 @@ def test_a_camera_that_moves_every_frame(oracle):
         assert builds[-1] > builds[11] + 2          # ... the fly-away climbs the ladder and comes down again
         assert V.KERNEL_PERSISTENT in kernels and kernels[-1] == V.KERNEL_CLUSTERED  # flat list beyond 64 diagonals, then back
         assert abs(ctx.scene_stats().range_diags - 2.0) < 1e-9  # back on the scene's own rung
+
+
+@pytest.mark.gpu
+def test_round4_boundary_additions(gpu_ctx, rt):
+    """ABI 4: the frame's kernel reports the shader clock it ran at (RtStats.shader_clock_mhz: a plausible MI355X clock after a PATH
+    frame, 0 after one of the reference's shaders), rtGetSceneStats says what rtSetScene made of the scene, and the two limits the
+    round-4 kernels rely on are refused at the door: max_depth beyond the 19 bits a path's depth is counted in, and a tile of 2^29
+    pixels or more."""
+    sph, mat = V.make_cover_scene(1, 11)
+    gpu_ctx.set_scene(sph, mat)
+    ss = gpu_ctx.scene_stats()
+    assert ss.cluster_builds == 1 and ss.n_spheres == len(sph) and ss.n_super == 0 and ss.n_clusters == 32
+    assert ss.range_diags == 2.0 and ss.base_range_diags == 2.0 and ss.flat_axis == 1 and 0.0 < ss.scene_build_ms < 1000.0
+    cam = V.make_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, 1.5, 0.1, 10.0)
+    gpu_ctx.render(cam, V.make_params(300, 200, spp=16, max_depth=50, seed=1))
+    assert 1000 <= gpu_ctx.stats().shader_clock_mhz <= 2600, gpu_ctx.stats().shader_clock_mhz
+    gpu_ctx.render_ubo(V.ubo_from_image(64, 48), V.RT_MODE_CH06)
+    assert gpu_ctx.stats().shader_clock_mhz == 0
+    with pytest.raises(rt.RtError) as e:
+        gpu_ctx.render(cam, V.make_params(64, 48, spp=1, max_depth=1 << 19, seed=1))
+    assert e.value.code == V.RT_ERR_INVALID
+    gpu_ctx.render(cam, V.make_params(64, 48, spp=1, max_depth=(1 << 19) - 1, seed=1))  # (the largest depth accepted)
+    with pytest.raises(rt.RtError) as e:  # 32768 x 16384 = 2^29 pixels: refused before anything is allocated
+        gpu_ctx.render_device(cam, V.make_params(32768, 16384, spp=1, max_depth=1, seed=1), 4096, 32768 * 4)
+    assert e.value.code == V.RT_ERR_INVALID
