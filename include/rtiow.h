@@ -221,9 +221,23 @@ int rtGetLastKernel(RtContext* ctx, uint32_t* kernel_out);
  * element on the GPU over host arrays — op 0 fma(a,b,c), 1 a/b, 2 sqrt(a),
  * 3 a*b, 4 a+b, 5 RNG draw, 6 fixed-point accumulate, 7 u64->float, 8 / 9 the kernels' own shortened square root / quotient
  * (to be compared with 2 / 1 on operands inside their stated ranges) — so a CPU/GPU rounding difference can be pinned to
- * a single operation.  No reference counterpart. */
+ * a single operation.  Ops 10-16: the pieces of the two-phase CH05/CH06 pixels (results are bit patterns, bit 31 set when
+ * the exact second phase ran): 10 v_rsq_f32(a); 11 / 12 the sky colour of (dy = a, dot(dir, dir) = b), two-phase / exact;
+ * 13 the sky colour of normalize(dir).y = a; 14 / 15 the normal colour of v = (a, b, c), two-phase / exact; 16 the sky
+ * table's answer for a alone.  No reference counterpart. */
 int rtSelfTestArith(RtContext* ctx, uint32_t op, const float* a, const float* b, const float* c,
                     float* out, uint32_t n);
+
+/* Every float unit_y in [lo, hi] at which the sky colour of raytrace06.comp:45-47 / raytrace05.comp:39-40 -- a function of
+ * normalize(dir).y alone -- differs from the colour of the float before it, found by evaluating the kernels' own arithmetic
+ * on every float of the range on the GPU (two billion for [-1, 1]; milliseconds).  The two-phase pixels of the CH kernels
+ * rest on the table tools/gen_ch_sky_table.py derives from the same step list on the host; the tests compare the two.
+ * `count` receives the number found, of which the first `cap` (in no particular order) are written.  Diagnostic. */
+typedef struct RtChSkyStep {
+    float unit_y;          /* first float with the new colour */
+    uint32_t before, after; /* packed r | g << 8 | b << 16 */
+} RtChSkyStep;
+int rtSelfTestChSkySteps(RtContext* ctx, float lo, float hi, RtChSkyStep* out, uint32_t cap, uint32_t* count);
 
 /* ---- several GPUs of one node, one process ---------------------------------------------------
  * The reference drives exactly one device (RTCHAP06/Vulkan.cpp:87-97; one queue family by assert,

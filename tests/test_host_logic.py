@@ -454,3 +454,40 @@ def test_fail_loudly_lets_a_clean_exit_through():
     for want in (0, 3):
         res = subprocess.run([sys.executable, "-c", code, str(want)], capture_output=True, text=True, timeout=300)
         assert res.returncode == want, (want, res.returncode, res.stderr[-500:])
+
+
+def test_ch_sky_table_is_what_its_generator_derives():
+    """csrc/rtiow_ch_sky_table.h -- the sky colour of raytrace06.comp:45-47 as a step function of normalize(dir).y, on which the first
+    phase of ch_kernel_rows' two-phase pixels rests -- is exactly what tools/gen_ch_sky_table.py generates: the script evaluates its
+    float32 restatement of the shader's sky arithmetic on all 25 million values unit_y + 1 can take, collects the 280 floats where the
+    colour changes, and checks on the host that every float within the guard band of a step is sent to the exact second phase and that
+    the table's colour holds for every float within the guard band of an un-flagged one.  (On the GPU, tests/test_gpu_ch_two_phase.py
+    finds the same 280 floats by evaluating the kernel's own code on all 2.1 billion floats of [-1, 1].)"""
+    import subprocess
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_ch_sky_table.py"), "--check"], capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stdout[-500:] + res.stderr[-1500:]
+    assert "280 changes in 179 zones" in res.stdout, res.stdout
+
+
+def test_ch_sky_steps_follow_the_quantiser():
+    """An independent look at the step list: the red byte trunc((1 - 0.5 t) * 255 + 0.5) steps where 127.5 t crosses k + 0.5, the green
+    byte where 76.5 t does (t = (unit_y + 1) / 2), the blue byte never -- 127 + 76 steps, the coinciding ones (3 (2k + 1) = 5 (2j + 1))
+    in one zone; every zone of the generator lies within 2e-6 of such a crossing and every crossing has its zone."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_ch_sky_table", os.path.join(ROOT, "tools", "gen_ch_sky_table.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    table, zones, steps = gen.build()
+    red = [(k + 0.5) / 127.5 for k in range(128) if (k + 0.5) / 127.5 <= 1.0]
+    green = [(j + 0.5) / 76.5 for j in range(77) if (j + 0.5) / 76.5 <= 1.0]
+    crossings = sorted(set(round(2.0 * t - 1.0, 9) for t in red + green))
+    merged = [crossings[0]]
+    for y in crossings[1:]:
+        if y - merged[-1] > 1e-6:
+            merged.append(y)
+    centres = [0.5 * (float(z[0]) + float(z[1])) for z in zones]
+    assert len(merged) == len(zones) == 179
+    assert max(abs(a - b) for a, b in zip(merged, centres)) < 2e-6
+    assert all((s[1] ^ s[2]) & 0xFF0000 == 0 for s in steps)  # blue never changes
+    assert steps[0][1] == 0xFFFFFF and int(gen.F(np.float32(1.0))) & 0xFF00FF == 0xFF0080  # white at the nadir, (0.5, 0.7, 1) at the zenith

@@ -91,6 +91,7 @@ SIGNATURES = {
     "rtSynchronize": (C.c_int, [_VP]),
     "rtGetLastKernel": (C.c_int, [_VP, C.POINTER(C.c_uint32)]),
     "rtSelfTestArith": (C.c_int, [_VP, C.c_uint32, _VP, _VP, _VP, _VP, C.c_uint32]),
+    "rtSelfTestChSkySteps": (C.c_int, [_VP, C.c_float, C.c_float, _VP, C.c_uint32, C.POINTER(C.c_uint32)]),
     "rtUboFromImage": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(RtUbo5)]),
     "rtCameraFromUbo": (C.c_int, [C.POINTER(RtUbo5), C.POINTER(RtCamera)]),
     "rtMakeCamera": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
@@ -342,6 +343,16 @@ class Context:
                                                   c.ctypes.data, out.ctypes.data, a.size),
                "rtSelfTestArith")
         return out
+
+    def selftest_ch_sky_steps(self, lo: float, hi: float, cap: int = 4096) -> np.ndarray:
+        """rtSelfTestChSkySteps: the floats in [lo, hi] where the CH shaders' sky colour changes, sorted, as a structured array
+        (unit_y, before, after)."""
+        out = np.zeros(cap, dtype=[("unit_y", np.float32), ("before", np.uint32), ("after", np.uint32)])
+        n = C.c_uint32(0)
+        _check(self._h, self._lib.rtSelfTestChSkySteps(self._h, lo, hi, out.ctypes.data, cap, C.byref(n)), "rtSelfTestChSkySteps")
+        if n.value > cap:
+            raise RtiowError(RT_ERR_INVALID, f"{n.value} steps, room for {cap}")
+        return np.sort(out[: n.value], order="unit_y")
 
 
 class MultiContext:

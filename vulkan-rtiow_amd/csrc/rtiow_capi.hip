@@ -722,12 +722,12 @@ int rtGetLastKernel(RtContext* ctx, uint32_t* kernel_out) {
 }
 
 // Arithmetic conformance probe: runs op over host arrays on the GPU
-// (0 fma, 1 div, 2 sqrt, 3 mul, 4 add, 5 RNG draw, 6 fixed-point accumulate, 7 u64->float, 8 / 9 the kernels' lean square root / quotient).  Used by the parity tests to
+// (0 fma, 1 div, 2 sqrt, 3 mul, 4 add, 5 RNG draw, 6 fixed-point accumulate, 7 u64->float, 8 / 9 the kernels' lean square root / quotient, 10-16 the pieces of the two-phase CH pixels: include/rtiow.h).  Used by the parity tests to
 // localise any CPU/GPU rounding difference to a single operation.
 int rtSelfTestArith(RtContext* ctx, uint32_t op, const float* a, const float* b, const float* c,
                     float* out, uint32_t n) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rtSelfTestArith: ctx is null");
-    if (!a || !b || !c || !out || n == 0 || op > 9)
+    if (!a || !b || !c || !out || n == 0 || op > 16)
         return fail(ctx, RT_ERR_INVALID, "rtSelfTestArith: bad arguments");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     float* d = nullptr;
@@ -741,6 +741,25 @@ int rtSelfTestArith(RtContext* ctx, uint32_t op, const float* a, const float* b,
     if (e == hipSuccess) e = hipMemcpy(out, d + 3 * size_t(n), bytes, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail_hip(ctx, e, "rtSelfTestArith");
+    return RT_OK;
+}
+
+int rtSelfTestChSkySteps(RtContext* ctx, float lo, float hi, RtChSkyStep* out, uint32_t cap, uint32_t* count) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rtSelfTestChSkySteps: ctx is null");
+    if (!out || !count || cap == 0 || !(lo <= hi) || !std::isfinite(lo) || !std::isfinite(hi))
+        return fail(ctx, RT_ERR_INVALID, "rtSelfTestChSkySteps: bad arguments");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    void* d = nullptr;
+    const size_t bytes = size_t(cap) * sizeof(RtChSkyStep);
+    RT_HIP(ctx, hipMalloc(&d, bytes + 16));
+    uint32_t* d_count = reinterpret_cast<uint32_t*>(static_cast<char*>(d) + bytes);
+    hipError_t e = hipMemsetAsync(d_count, 0, 4, ctx->stream);
+    if (e == hipSuccess) e = rtiow::launch_ch_sky_steps(lo, hi, static_cast<RtChSkyStep*>(d), cap, d_count, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(count, d_count, 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out, d, size_t(*count < cap ? *count : cap) * sizeof(RtChSkyStep), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail_hip(ctx, e, "rtSelfTestChSkySteps");
     return RT_OK;
 }
 

@@ -143,6 +143,7 @@ struct ChArgs {
     uint32_t tiles_form;     // != 0: one lane per pixel in 16x16 tiles, as the reference dispatches (RtParams.kernel = 1)
     uint32_t rows_per_wave;  // (set by launch_ch) rows of the frame a wave of ch_kernel_rows renders
     uint32_t vector_store;   // (set by launch_ch) destination rows are 16-byte aligned
+    uint32_t row_blocks, row_block_stride;  // (set by launch_ch) two-phase kernel: grid row g renders row block g * stride mod row_blocks
 };
 
 // Chunks of the persistent kernels' pixel queue.  One chunk = 32 pixels = one 128-byte line of the frame: all its
@@ -225,6 +226,8 @@ enum : uint32_t {
 };
 
 hipError_t launch_ch(const ChArgs& a, hipStream_t stream);
+// rtSelfTestChSkySteps: every float in [lo, hi] where the sky colour of raytrace06.comp:45-47 changes (see ch_sky_steps_kernel)
+hipError_t launch_ch_sky_steps(float lo, float hi, RtChSkyStep* out, uint32_t cap, uint32_t* count, hipStream_t stream);
 // the primary pass's cone cull run on the host (rtConeSelfTestHost): see rtiow_kernels.hip
 int cone_selftest_host(const RtCamera& cam, uint32_t width, uint32_t height, uint32_t pix_lo, uint32_t pix_hi,
                        const float* range_center, float range_rmax, const RtSphere* spheres, uint32_t n_spheres,

@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include "rtiow_device.h"
 #include "rtiow_rng.h"
@@ -325,6 +326,23 @@ DI uint32_t ch_unorm8(float x) {
     return BOUNDED ? q : (q < 255u ? q : 255u);
 }
 
+// raytrace06.comp:41-43 from v = rayAt(t) - centre and l = sqrt(dot(v, v)): normalize(v) = v / l, colour 0.5 * (N + 1), rgba8
+template <bool LEAN>
+DI uint32_t ch_normal_colour(f3 v, float l) {
+    auto div_ = [](float a, float b) { return LEAN ? lean_div(a, b) : a / b; };
+    const f3 nrm = mk(div_(v.x, l), div_(v.y, l), div_(v.z, l));
+    const f3 col = mk(0.5f * (nrm.x + 1), 0.5f * (nrm.y + 1), 0.5f * (nrm.z + 1));
+    return pack_rgb(ch_unorm8<LEAN>(col.x), ch_unorm8<LEAN>(col.y), ch_unorm8<LEAN>(col.z));  // alpha byte 0 (raytrace06.comp:66)
+}
+// raytrace06.comp:45-47 from unit_y = normalize(dir).y, the only component of it the shaders read
+template <bool LEAN>
+DI uint32_t ch_sky_colour(float unit_y) {
+    const float t = 0.5f * (unit_y + 1.0f);
+    const float kk = 1.0f - t;
+    const f3 col = mk(1.0f * kk + 0.5f * t, 1.0f * kk + 0.7f * t, 1.0f * kk + 1.0f * t);
+    return pack_rgb(ch_unorm8<LEAN>(col.x), ch_unorm8<LEAN>(col.y), ch_unorm8<LEAN>(col.z));
+}
+
 // one pixel: raytrace06.comp:21-48 / raytrace05.comp:21-40 from the hoisted products (xx = dir.x*dir.x, ox = oc.x*dir.x, ...)
 template <bool LEAN>
 DI uint32_t ch_pixel(uint32_t mode, const ChConst& k, float dx, float xx, float ox, float dy, float yy, float oy) {
@@ -338,35 +356,140 @@ DI uint32_t ch_pixel(uint32_t mode, const ChConst& k, float dx, float xx, float 
     // constants -- five instructions and two LDS operands per pixel less.  (The full kernels, launched for any other UBO, add it up.)
     const float qb = LEAN ? k.qb : 2.0f * ((ox + oy) + k.oz_dz);
     const float disc = qb * qb - 4 * qa * k.qc;
-    f3 col;
-    bool shaded = false;
     if (mode == RT_MODE_CH05) {
-        if (disc > 0) {  // raytrace05.comp:29,35-37
-            col = mk(1.0f, 0.0f, 0.0f);
-            shaded = true;
-        }
+        if (disc > 0) return pack_rgb(ch_unorm8<LEAN>(1.0f), ch_unorm8<LEAN>(0.0f), ch_unorm8<LEAN>(0.0f));  // raytrace05.comp:29,35-37
     } else {
         const float t = (disc < 0) ? -1.0f : div_(-qb - sqrt_(disc), 2.0f * qa);
         if (t > 0.0f) {  // raytrace06.comp:39-43
             const f3 r = mk(0.0f + dx * t, 0.0f + dy * t, 0.0f + k.dz * t);
             const f3 v = mk(r.x - 0.0f, r.y - 0.0f, r.z - (-1.0f));
-            const float l = sqrt_(gdot(v, v));  // normalize(v) = v / sqrt(dot(v, v))
-            const f3 nrm = mk(div_(v.x, l), div_(v.y, l), div_(v.z, l));
-            col = mk(0.5f * (nrm.x + 1), 0.5f * (nrm.y + 1), 0.5f * (nrm.z + 1));
-            shaded = true;
+            return ch_normal_colour<LEAN>(v, sqrt_(gdot(v, v)));  // normalize(v) = v / sqrt(dot(v, v))
         }
     }
-    if (!shaded) {  // raytrace06.comp:45-47: only the y component of normalize(dir) is used
-        const float unit_y = div_(dy, sqrt_(qa));
-        const float t = 0.5f * (unit_y + 1.0f);
-        const float kk = 1.0f - t;
-        col = mk(1.0f * kk + 0.5f * t, 1.0f * kk + 0.7f * t, 1.0f * kk + 1.0f * t);
+    return ch_sky_colour<LEAN>(div_(dy, sqrt_(qa)));  // raytrace06.comp:45-47: only the y component of normalize(dir) is used
+}
+
+// ---- Two-phase pixels: the bytes of the frame without every rounding of the way there ---------------------------------------------
+// What the shaders store is 24 bits per pixel, and both of their colour formulas end in a quantiser that forgets almost everything
+// the correctly rounded roots and quotients before it were careful about.  The two-phase form of ch_kernel_rows (Ziv's strategy, as
+// correctly rounded math libraries use it) computes each pixel from one-ulp hardware approximations first, together with a proof
+// that the quantised result cannot depend on the difference, and falls back to the exact arithmetic above -- ch_pixel<true>'s own
+// functions -- for the pixels where that proof does not hold (about 1 in 10^4 sky pixels, 1 in 1400 sphere pixels).  Same bytes:
+//   * SKY.  The colour is a function F of the single float unit_y = RN(dy / RN(sqrt(qa))) (ch_sky_colour), a step function with 280
+//     steps in 179 zones a few ulps wide; tools/gen_ch_sky_table.py finds every one of them by evaluating the shader's arithmetic on
+//     all 25 million values unit_y + 1 can take, and writes rtiow_ch_sky_table.h: per bucket of 1/256 of unit_y one zone [lo, hi]
+//     widened by G = 2^-21 either side and the colours below and above it.  Phase 1: y1 = dy * v_rsq_f32(qa).  With r = dy / sqrt(qa)
+//     (|r| <= 1 + 2^-22: qa contains dy * dy) and h = 2^-24, unit_y = r (1 + e2) / (1 + e1) with |e1|, |e2| <= h lies within 2 h |r|
+//     (1 + h) of r, and y1 = r (1 + e6)(1 + e7) with |e6| <= 2 h (one ulp: tests/test_gpu_parity.py measures it on every float of a
+//     binade pair), |e7| <= h within 3 h |r| (1 + h): |y1 - unit_y| < 5.01 h < 0.63 G.  So y1 < lo means unit_y lies below the zone's
+//     first step, y1 > hi means it lies at or above the last, and F(unit_y) is the table's colour; anything else is computed.
+//   * SPHERE (raytrace06's normal colour).  t is exact as before (it is multiplied into three coordinates, and its error would be
+//     amplified 250-fold on the way to a byte); v and d = dot(v, v) are the shader's.  Per channel, rho = v_c / sqrt(d) (|rho| <= 1 +
+//     2^-22) and Y = 127.5 rho + 128.  The shader's y = RN(RN(0.5 RN(n + 1) * 255) + 0.5) with n = RN(v_c / RN(sqrt(d))): |n - rho| <=
+//     2 h |rho| (1 + h), RN(n + 1) adds at most 2 h, the product and the sum at most 2^-17 each (y < 256):  |y - Y| <= 127.5 * 4.01 h +
+//     2^-16 < 4.6e-5.  Phase 1: y1 = fma(v_c * v_rsq_f32(d), 127.5, 128): |y1 - Y| <= 127.5 * 3.01 h + 2^-17 < 3.1e-5.  The byte is
+//     trunc(y) (0.49 < y < 255.51): when fract(y1) lies in [D, 1 - D] with D = 2^-13 = 1.22e-4 > 1.6 * 7.7e-5, y and y1 lie between the same
+//     two integers.  Otherwise the pixel's three channels are divided out exactly.
+// The table sits in LDS (8 KB per workgroup, one ds_read_b128 per pixel, neighbours read the same entry).
+#include "rtiow_ch_sky_table.h"
+alignas(16) __device__ const uint32_t ch_sky_table_words[4u * RTIOW_CH_SKY_BUCKETS] = RTIOW_CH_SKY_TABLE_WORDS;
+constexpr float kChSkyScale = 256.0f;          // bucket = trunc(fma(y1, 256, 256)): 0 .. 512
+constexpr float kChSphereGuard = 0x1p-13f;     // D
+constexpr uint32_t kChPhase2Flag = 1u << 31;   // (rtSelfTestArith ops 11, 14, 16 report the phase in the alpha byte's top bit)
+
+DI float ch_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+DI uint32_t ch_cvt_u32(float y) {
+    uint32_t q;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(y));
+    return q;
+}
+// phase 1 of the sky: the table's colour for y1; `second`: y1 lies within G of a step and the pixel has to be computed.  `table`: the
+// 513 entries, in LDS for the kernel.  (An index past the table cannot happen for finite y1 <= 1 + 2^-21; LDS reads out of range return 0
+// on this hardware.)
+DI uint32_t ch_sky_phase1(const uint4* table, float y1, bool& second) {
+    const uint4 e = table[ch_cvt_u32(fma_(y1, kChSkyScale, kChSkyScale))];
+    const bool not_below = y1 >= __uint_as_float(e.x);
+    second = not_below && y1 <= __uint_as_float(e.y);
+    return not_below ? e.w : e.z;
+}
+DI uint32_t ch_sky_two_phase(const uint4* table, float dy, float qa) {
+    bool second;
+    const uint32_t c = ch_sky_phase1(table, dy * ch_rsq(qa), second);
+    if (__builtin_expect(!second, 1)) return c;
+    return ch_sky_colour<true>(lean_div(dy, lean_sqrt(qa))) | kChPhase2Flag;
+}
+DI uint32_t ch_normal_two_phase(f3 v) {
+    const float d = gdot(v, v);
+    const float inv = ch_rsq(d);
+    const float yx = fma_(v.x * inv, 127.5f, 128.0f), yy = fma_(v.y * inv, 127.5f, 128.0f), yz = fma_(v.z * inv, 127.5f, 128.0f);
+    const float fx = __builtin_amdgcn_fractf(yx) - 0.5f, fy = __builtin_amdgcn_fractf(yy) - 0.5f, fz = __builtin_amdgcn_fractf(yz) - 0.5f;
+    const float worst = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(fx), __builtin_fabsf(fy)), __builtin_fabsf(fz));
+    if (__builtin_expect(worst <= 0.5f - kChSphereGuard, 1)) return pack_rgb(ch_cvt_u32(yx), ch_cvt_u32(yy), ch_cvt_u32(yz));
+    return ch_normal_colour<true>(v, lean_sqrt(d)) | kChPhase2Flag;
+}
+// Is the pixel the sphere's (raytrace05.comp:29 disc > 0; raytrace06.comp:28,39 !(disc < 0), then t > 0 -- see below)?  disc = RN(qb qb -
+// RN(4 qa qc)): the sign of a float difference is the sign of the exact one, so the product m = RN(qa * (4 qc)) (4 qc = 3 exactly, and
+// RN(4 qa * qc) = RN(qa * 3): a power of two changes no rounding) is compared with qb * qb without being subtracted -- m < qb qb for
+// CH05, m <= qb qb for CH06, which for the finite positive numbers of the lean range is m < the float after qb qb: one comparison
+// against a per-frame bound either way.
+DI float ch_sphere_bound(uint32_t mode, const ChConst& k) {
+    const float qbqb = k.qb * k.qb;
+    return mode == RT_MODE_CH05 ? qbqb : __uint_as_float(__float_as_uint(qbqb) + 1u);
+}
+DI bool ch_is_sphere(const ChConst& k, float bound, float qa) { return qa * (4 * k.qc) < bound; }
+// the sphere's colour, two-phase (the pixel is known to be the sphere's by ch_is_sphere).  raytrace06.comp:39 also asks for t > 0:
+// with disc >= 0 that is -qb > sqrt(disc), true for every such pixel when focalLength > 0 (qb = -2 focalLength and disc <= qb^2 / 4)
+// and for none when it is negative (the sphere is behind the camera: the whole frame is sky, these pixels by the exact arithmetic).
+DI uint32_t ch_sphere_two_phase(uint32_t mode, const ChConst& k, float dx, float dy, float qa) {
+    if (mode == RT_MODE_CH05) return pack_rgb(255u, 0u, 0u);  // = ch_unorm8 of (1, 0, 0)
+    const float disc = k.qb * k.qb - 4 * qa * k.qc;
+    const float t = lean_div(-k.qb - lean_sqrt(disc), 2.0f * qa);
+    if (__builtin_expect(!(t > 0.0f), 0)) return ch_sky_colour<true>(lean_div(dy, lean_sqrt(qa))) | kChPhase2Flag;
+    // rayAt's "origin + t * dir" adds +0 to each product in the shader; that turns a -0 into +0 and nothing else, and a zero coordinate of
+    // either sign squares to +0 and divides to a zero that is 0.5 two operations later: the additions are left out (the second phase is
+    // ch_normal_colour on the same v: equal wherever v is not a zero, and the bytes are equal there too)
+    return ch_normal_two_phase(mk(dx * t, dy * t, k.dz * t - (-1.0f)));
+}
+// A lane's four pixels of a row, two-phase (LEAN preconditions: launch_ch).  The sky's first phase runs for all four side by side, without
+// a branch (one wait for four table reads), whenever a lane of the wave has a sky pixel among them; sphere pixels and second phases follow
+// under branches that most waves skip.  (The sphere's first phase side by side for waves that are all sphere: bit-identical, and slower --
+// 0.17 against 0.145 ms at 16384 x 8192; hipcc keeps the four chains one after the other and materialises the flags in registers.)
+// Returns the four pixels, alpha 0.
+DI uint4 ch_quad_two_phase(uint32_t mode, const ChConst& k, const uint4* table, float4 dx4, float4 xx4, float dy, float yy) {
+    const float dx[4] = {dx4.x, dx4.y, dx4.z, dx4.w}, xx[4] = {xx4.x, xx4.y, xx4.z, xx4.w};
+    const float bound = ch_sphere_bound(mode, k);
+    float qa[4];
+    bool sphere[4], second[4] = {false, false, false, false};
+    uint32_t px[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        qa[i] = (xx[i] + yy) + k.zz;
+        sphere[i] = ch_is_sphere(k, bound, qa[i]);
     }
-    return pack_rgb(ch_unorm8<LEAN>(col.x), ch_unorm8<LEAN>(col.y), ch_unorm8<LEAN>(col.z));  // alpha byte 0 (raytrace06.comp:66)
+    const bool all_sphere = sphere[0] && sphere[1] && sphere[2] && sphere[3], any_sphere = sphere[0] || sphere[1] || sphere[2] || sphere[3];
+    if (__builtin_amdgcn_ballot_w64(!all_sphere) != 0ull) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            px[i] = ch_sky_phase1(table, dy * ch_rsq(qa[i]), second[i]);
+            second[i] = second[i] && !sphere[i];
+        }
+        if (__builtin_amdgcn_ballot_w64(second[0] || second[1] || second[2] || second[3]) != 0ull) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (second[i]) px[i] = ch_sky_colour<true>(lean_div(dy, lean_sqrt(qa[i])));
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(any_sphere) != 0ull) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (sphere[i]) px[i] = ch_sphere_two_phase(mode, k, dx[i], dy, qa[i]) & ~kChPhase2Flag;
+    }
+    return make_uint4(px[0], px[1], px[2], px[3]);
 }
 
 constexpr uint32_t kChTileCols = 256;  // columns of a workgroup's tile: 64 lanes x 4 pixels
-template <bool LEAN>
+enum : int { kChFull = 0, kChLean = 1, kChTwoPhase = 2 };  // hipcc's roots and quotients / their cores / two-phase pixels
+template <int FORM>
 __global__ __launch_bounds__(256) void ch_kernel_rows(ChArgs a) {
     __shared__ float4 col_dx[kChTileCols / 4], col_xx[kChTileCols / 4], col_ox[kChTileCols / 4];  // per column, four to a lane
     __shared__ float row_dy[64], row_yy[64], row_oy[64];                                          // per row of the tile
@@ -379,30 +502,84 @@ __global__ __launch_bounds__(256) void ch_kernel_rows(ChArgs a) {
         const float dx = ((k.llc_x + k.hx * u) + 0.0f) - 0.0f;
         reinterpret_cast<float*>(col_dx)[threadIdx.x] = dx;
         reinterpret_cast<float*>(col_xx)[threadIdx.x] = dx * dx;
-        reinterpret_cast<float*>(col_ox)[threadIdx.x] = k.oc_x * dx;
+        if (FORM == kChFull) reinterpret_cast<float*>(col_ox)[threadIdx.x] = k.oc_x * dx;
     }
     if (threadIdx.x < rows_per_block) {  // raytrace06.comp:58,60: v and dir.y of the tile's rows (0 * u = +0)
         const float v = static_cast<float>(row0 + threadIdx.x) / (a.ubo.imageHeight - 1);
         const float dy = ((k.llc_y + 0.0f) + k.vy * v) - 0.0f;
         row_dy[threadIdx.x] = dy;
         row_yy[threadIdx.x] = dy * dy;
-        row_oy[threadIdx.x] = k.oc_y * dy;
+        if (FORM == kChFull) row_oy[threadIdx.x] = k.oc_y * dy;
     }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t c = col0 + 4u * lane;
     if (c >= a.width) return;
-    const float4 dx4 = col_dx[lane], xx4 = col_xx[lane], ox4 = col_ox[lane];
+    const float4 dx4 = col_dx[lane], xx4 = col_xx[lane];
+    const float4 ox4 = FORM == kChFull ? col_ox[lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const bool vec = c + 3u < a.width && a.vector_store != 0u;  // a whole, 16-byte aligned quad
     for (uint32_t j = 0; j < a.rows_per_wave; ++j) {
         const uint32_t lr = wave * a.rows_per_wave + j, row = row0 + lr;
         if (row >= a.height) break;
-        const float dy = row_dy[lr], yy = row_yy[lr], oy = row_oy[lr];  // LDS broadcast
+        const float dy = row_dy[lr], yy = row_yy[lr], oy = FORM == kChFull ? row_oy[lr] : 0.0f;  // LDS broadcast
         uint4 px;
-        px.x = ch_pixel<LEAN>(a.mode, k, dx4.x, xx4.x, ox4.x, dy, yy, oy);
-        px.y = ch_pixel<LEAN>(a.mode, k, dx4.y, xx4.y, ox4.y, dy, yy, oy);
-        px.z = ch_pixel<LEAN>(a.mode, k, dx4.z, xx4.z, ox4.z, dy, yy, oy);
-        px.w = ch_pixel<LEAN>(a.mode, k, dx4.w, xx4.w, ox4.w, dy, yy, oy);
+        px.x = ch_pixel<FORM == kChLean>(a.mode, k, dx4.x, xx4.x, ox4.x, dy, yy, oy);
+        px.y = ch_pixel<FORM == kChLean>(a.mode, k, dx4.y, xx4.y, ox4.y, dy, yy, oy);
+        px.z = ch_pixel<FORM == kChLean>(a.mode, k, dx4.z, xx4.z, ox4.z, dy, yy, oy);
+        px.w = ch_pixel<FORM == kChLean>(a.mode, k, dx4.w, xx4.w, ox4.w, dy, yy, oy);
+        uint32_t* out = a.dst + static_cast<size_t>(row) * a.dst_stride + c;
+        if (vec) {
+            *reinterpret_cast<uint4*>(out) = px;
+        } else {  // the ragged right edge, or a destination that is not 16-byte aligned
+            out[0] = px.x;
+            if (c + 1u < a.width) out[1] = px.y;
+            if (c + 2u < a.width) out[2] = px.z;
+            if (c + 3u < a.width) out[3] = px.w;
+        }
+    }
+}
+
+// ch_kernel_rows<kChTwoPhase>: the two-phase pixels.  With a dozen instructions per sky pixel the kernel is bound by how its stores reach
+// HBM where the frame is sky and by the vector ALU where it is the sphere, and the sphere sits in the middle of the frame: dealt in raster
+// order, workgroups of the same kind run at the same time (and, tile columns recurring with the period of the dispatcher's round over XCDs
+// and CUs, on the same CUs).  So the tiles are dealt in an order that mixes them: row block rb of the grid renders row block rb * stride mod
+// n (stride near the golden section of n, coprime with it) and starts three tile columns further right than the block before it
+// (tools/ch_bandwidth.py, 16384^2 / 16384 x 8192: 0.231 / 0.162 ms in raster order, 0.212 / 0.145 so).  Each lane computes the values of
+// its own four columns (lean quotients: launch_ch checks their operands too), each wave those of its own rows; only the sky table is shared
+// by the workgroup.
+template <>
+__global__ __launch_bounds__(256) void ch_kernel_rows<kChTwoPhase>(ChArgs a) {
+    __shared__ uint4 sky_table[RTIOW_CH_SKY_BUCKETS];
+    __shared__ float row_dy[4][16], row_yy[4][16];  // per wave: dir.y and its square for the wave's rows (rows_per_wave <= 16)
+    const ChConst k = ch_constants(a.ubo);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t tiles_x = (a.width + kChTileCols - 1u) / kChTileCols;
+    const uint32_t grid_row = blockIdx.x / tiles_x;
+    const uint32_t rb = static_cast<uint32_t>((static_cast<unsigned long long>(grid_row) * a.row_block_stride) % a.row_blocks);
+    const uint32_t c = ((blockIdx.x % tiles_x + 3u * grid_row) % tiles_x) * kChTileCols + 4u * lane;
+    const uint32_t row0 = (rb * 4u + wave) * a.rows_per_wave;
+    for (uint32_t i = threadIdx.x; i < RTIOW_CH_SKY_BUCKETS; i += 256u) sky_table[i] = reinterpret_cast<const uint4*>(ch_sky_table_words)[i];
+    float dx[4], xx[4];
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; ++i) {  // raytrace06.comp:57,59: u and dir.x of this lane's columns (0 * v = +0: v is finite and >= 0)
+        const float u = lean_div(static_cast<float>(c + i), a.ubo.imageWidth - 1);
+        dx[i] = ((k.llc_x + k.hx * u) + 0.0f) - 0.0f;
+        xx[i] = dx[i] * dx[i];
+    }
+    if (lane < a.rows_per_wave) {  // raytrace06.comp:58,60: v and dir.y of this wave's rows (0 * u = +0)
+        const float v = lean_div(static_cast<float>(row0 + lane), a.ubo.imageHeight - 1);
+        const float dy = ((k.llc_y + 0.0f) + k.vy * v) - 0.0f;
+        row_dy[wave][lane] = dy;
+        row_yy[wave][lane] = dy * dy;
+    }
+    __syncthreads();
+    if (c >= a.width) return;
+    const bool vec = c + 3u < a.width && a.vector_store != 0u;  // a whole, 16-byte aligned quad
+    const float4 dx4 = make_float4(dx[0], dx[1], dx[2], dx[3]), xx4 = make_float4(xx[0], xx[1], xx[2], xx[3]);
+    for (uint32_t j = 0; j < a.rows_per_wave; ++j) {
+        const uint32_t row = row0 + j;
+        if (row >= a.height) break;
+        const uint4 px = ch_quad_two_phase(a.mode, k, sky_table, dx4, xx4, row_dy[wave][j], row_yy[wave][j]);
         uint32_t* out = a.dst + static_cast<size_t>(row) * a.dst_stride + c;
         if (vec) {
             *reinterpret_cast<uint4*>(out) = px;
@@ -3175,11 +3352,34 @@ __global__ void arith_kernel(uint32_t op, const float* a, const float* b, const 
             break;
         case 8: r = lean_sqrt(a[i]); break;      // the PATH and CH kernels' lean forms themselves (psqrt / pdiv; ch_pixel<LEAN>):
         case 9: r = lean_div(a[i], b[i]); break; // against sqrtf and / on operands inside their preconditions
+        // the two-phase CH pixels piece by piece (results are bit patterns; bit 31 set: the second phase ran)
+        case 10: r = ch_rsq(a[i]); break;                                                              // the instruction itself: one ulp?
+        case 11: r = __uint_as_float(ch_sky_two_phase(reinterpret_cast<const uint4*>(ch_sky_table_words), a[i], b[i])); break;  // (dy, qa)
+        case 12: r = __uint_as_float(ch_sky_colour<true>(lean_div(a[i], lean_sqrt(b[i])))); break;    // the exact sky of (dy, qa)
+        case 13: r = __uint_as_float(ch_sky_colour<true>(a[i])); break;                                // F(unit_y)
+        case 14: r = __uint_as_float(ch_normal_two_phase(mk(a[i], b[i], c[i]))); break;                // the normal colour of v
+        case 15: { const f3 v = mk(a[i], b[i], c[i]); r = __uint_as_float(ch_normal_colour<true>(v, lean_sqrt(gdot(v, v)))); break; }
+        case 16: { bool second; const uint32_t col = ch_sky_phase1(reinterpret_cast<const uint4*>(ch_sky_table_words), a[i], second); r = __uint_as_float(second ? kChPhase2Flag : col); break; }  // the table alone
         default: break;
     }
     out[i] = r;
 }
 
+// Every float unit_y in [lo, hi] at which the sky colour F (ch_sky_colour<true>, the shader's arithmetic) differs from F of the
+// float before it: the step list tools/gen_ch_sky_table.py derives on the host from its own restatement, here from the device code
+// itself on all two billion floats (tests/test_gpu_parity.py compares the two).  key: floats in ascending order, -k for negative ones.
+DI float ch_float_of_key(long long k) { return __uint_as_float(k < 0 ? static_cast<uint32_t>(-k) | 0x80000000u : static_cast<uint32_t>(k)); }
+__global__ __launch_bounds__(256) void ch_sky_steps_kernel(long long key_lo, unsigned long long n, RtChSkyStep* out, uint32_t cap, uint32_t* count) {
+    const unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * 256ull + threadIdx.x;
+    if (i >= n) return;
+    const long long key = key_lo + static_cast<long long>(i);
+    const float y = ch_float_of_key(key);
+    const uint32_t before = ch_sky_colour<true>(ch_float_of_key(key - 1)), after = ch_sky_colour<true>(y);
+    if (before != after) {
+        const uint32_t at = atomicAdd(count, 1u);
+        if (at < cap) out[at] = RtChSkyStep{y, before, after};
+    }
+}
 // ============================================================================
 // chunk order for the next frame (cost-ordered dequeue): one workgroup, counting sort on 1024 cost classes
 // ============================================================================
@@ -3300,6 +3500,14 @@ hipError_t launch_ch(const ChArgs& args, hipStream_t stream) {
         hipLaunchKernelGGL(ch_kernel_tiles, dim3(tiles), dim3(256), 0, stream, a);
         return hipGetLastError();
     }
+    // the lean square roots and quotients (lean_sqrt, lean_div) for a camera of moderate proportions, hipcc's full forms otherwise
+    auto moderate = [](float v) { return std::fabs(v) >= 0x1p-20f && std::fabs(v) <= 0x1p20f; };
+    const bool lean = moderate(a.ubo.viewportWidth) && moderate(a.ubo.viewportHeight) && moderate(a.ubo.focalLength) &&
+                      !debug_knob("RTIOW_DEBUG_CH_FULL");  // (the variable: A/B and parity tests)
+    // ... and of those the two-phase pixels, whose kernel also takes u = column / (imageWidth - 1) and v by the lean quotient: divisors in
+    // [1, 2^24] (RTIOW_DEBUG_CH_LEAN, knobs build: the exact lean kernel, for A/B and parity tests)
+    auto countable = [](float v) { return v - 1.0f >= 1.0f && v - 1.0f <= 0x1p24f; };
+    const bool two_phase = lean && countable(a.ubo.imageWidth) && countable(a.ubo.imageHeight) && !debug_knob("RTIOW_DEBUG_CH_LEAN");
     // rows a wave renders: enough workgroups to fill the chip eight times over first (the reference's 800x608 frame is
     // launch-bound: 4 rows per workgroup, 608 workgroups), then up to 16 so that the per-column values are reused
     const uint32_t tiles_x = (a.width + kChTileCols - 1u) / kChTileCols;
@@ -3307,13 +3515,19 @@ hipError_t launch_ch(const ChArgs& args, hipStream_t stream) {
     while (rpw < 16u && static_cast<unsigned long long>(tiles_x) * ((a.height + 8u * rpw - 1u) / (8u * rpw)) >= 2048ull) rpw *= 2u;
     a.rows_per_wave = rpw;
     a.vector_store = (reinterpret_cast<uintptr_t>(a.dst) % 16u == 0u && a.dst_stride % 4u == 0u) ? 1u : 0u;
-    const uint32_t blocks = tiles_x * ((a.height + 4u * rpw - 1u) / (4u * rpw));
-    // the lean square roots and quotients (lean_sqrt, lean_div) for a camera of moderate proportions, hipcc's full forms otherwise
-    auto moderate = [](float v) { return std::fabs(v) >= 0x1p-20f && std::fabs(v) <= 0x1p20f; };
-    const bool lean = moderate(a.ubo.viewportWidth) && moderate(a.ubo.viewportHeight) && moderate(a.ubo.focalLength) &&
-                      !debug_knob("RTIOW_DEBUG_CH_FULL");  // (the variable: A/B and parity tests)
-    if (lean) hipLaunchKernelGGL(ch_kernel_rows<true>, dim3(blocks), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(ch_kernel_rows<false>, dim3(blocks), dim3(256), 0, stream, a);
+    a.row_blocks = (a.height + 4u * rpw - 1u) / (4u * rpw);
+    const uint32_t blocks = tiles_x * a.row_blocks;
+    // the two-phase kernel's order of row blocks: a stride near the golden section of their number, coprime with it (1: raster order)
+    a.row_block_stride = 1u;
+    if (a.row_blocks > 4u && !debug_knob("RTIOW_DEBUG_CH_RASTER")) {
+        auto gcd = [](uint32_t x, uint32_t y) { while (y) { const uint32_t t = x % y; x = y; y = t; } return x; };
+        uint32_t stride = static_cast<uint32_t>(a.row_blocks * 0.6180339887) | 1u;
+        while (gcd(stride, a.row_blocks) != 1u) stride += 2u;
+        a.row_block_stride = stride % a.row_blocks;
+    }
+    if (two_phase) hipLaunchKernelGGL(ch_kernel_rows<kChTwoPhase>, dim3(blocks), dim3(256), 0, stream, a);
+    else if (lean) hipLaunchKernelGGL(ch_kernel_rows<kChLean>, dim3(blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(ch_kernel_rows<kChFull>, dim3(blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -3555,6 +3769,19 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
         g.fine_until = (g.chunk_until == ~0u && a.chunk_order != nullptr && div != 0u && g.pool_pix > g.fine_pix && small_frame) ? g.total_pix / 8u / div : 0u;
     }
     hipLaunchKernelGGL(kernel_fn, dim3(static_cast<uint32_t>(grid)), dim3(threads), lds, stream, a, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_ch_sky_steps(float lo, float hi, RtChSkyStep* out, uint32_t cap, uint32_t* count, hipStream_t stream) {
+    auto key_of = [](float x) {
+        uint32_t b;
+        std::memcpy(&b, &x, 4);
+        return (b & 0x80000000u) ? -static_cast<long long>(b & 0x7FFFFFFFu) : static_cast<long long>(b);
+    };
+    const long long k0 = key_of(lo), k1 = key_of(hi);
+    if (k1 < k0) return hipErrorInvalidValue;
+    const unsigned long long n = static_cast<unsigned long long>(k1 - k0) + 1ull;
+    hipLaunchKernelGGL(ch_sky_steps_kernel, dim3(static_cast<uint32_t>((n + 255ull) / 256ull)), dim3(256), 0, stream, k0, n, out, cap, count);
     return hipGetLastError();
 }
 
