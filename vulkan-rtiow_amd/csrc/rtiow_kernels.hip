@@ -544,27 +544,27 @@ __global__ __launch_bounds__(256) void ch_kernel_rows(ChArgs a) {
 // order, workgroups of the same kind run at the same time (and, tile columns recurring with the period of the dispatcher's round over XCDs
 // and CUs, on the same CUs).  So the tiles are dealt in an order that mixes them: row block rb of the grid renders row block rb * stride mod
 // n (stride near the golden section of n, coprime with it) and starts three tile columns further right than the block before it
-// (tools/ch_bandwidth.py, 16384^2 / 16384 x 8192: 0.231 / 0.162 ms in raster order, 0.212 / 0.145 so).  Each lane computes the values of
-// its own four columns (lean quotients: launch_ch checks their operands too), each wave those of its own rows; only the sky table is shared
-// by the workgroup.
+// (tools/ch_bandwidth.py, 16384^2 / 16384 x 8192: 0.231 / 0.162 ms in raster order, 0.212 / 0.145 so).  Per-column values come from
+// LDS as in the other forms (u and v by the lean quotient: launch_ch checks their operands too), each wave computes those of its own rows.
+// (Sixteen waves around one copy of the table instead of four: slower at every size, 0.237 against 0.222 ms at 16384^2.)
 template <>
 __global__ __launch_bounds__(256) void ch_kernel_rows<kChTwoPhase>(ChArgs a) {
     __shared__ uint4 sky_table[RTIOW_CH_SKY_BUCKETS];
+    __shared__ float4 col_dx[kChTileCols / 4], col_xx[kChTileCols / 4];  // per column of the tile, four to a lane
     __shared__ float row_dy[4][16], row_yy[4][16];  // per wave: dir.y and its square for the wave's rows (rows_per_wave <= 16)
     const ChConst k = ch_constants(a.ubo);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t tiles_x = (a.width + kChTileCols - 1u) / kChTileCols;
     const uint32_t grid_row = blockIdx.x / tiles_x;
     const uint32_t rb = static_cast<uint32_t>((static_cast<unsigned long long>(grid_row) * a.row_block_stride) % a.row_blocks);
-    const uint32_t c = ((blockIdx.x % tiles_x + 3u * grid_row) % tiles_x) * kChTileCols + 4u * lane;
+    const uint32_t col0 = ((blockIdx.x % tiles_x + 3u * grid_row) % tiles_x) * kChTileCols;
     const uint32_t row0 = (rb * 4u + wave) * a.rows_per_wave;
     for (uint32_t i = threadIdx.x; i < RTIOW_CH_SKY_BUCKETS; i += 256u) sky_table[i] = reinterpret_cast<const uint4*>(ch_sky_table_words)[i];
-    float dx[4], xx[4];
-#pragma unroll
-    for (uint32_t i = 0; i < 4u; ++i) {  // raytrace06.comp:57,59: u and dir.x of this lane's columns (0 * v = +0: v is finite and >= 0)
-        const float u = lean_div(static_cast<float>(c + i), a.ubo.imageWidth - 1);
-        dx[i] = ((k.llc_x + k.hx * u) + 0.0f) - 0.0f;
-        xx[i] = dx[i] * dx[i];
+    if (threadIdx.x < kChTileCols) {  // raytrace06.comp:57,59: u and dir.x of this thread's column (0 * v = +0: v is finite and >= 0)
+        const float u = lean_div(static_cast<float>(col0 + threadIdx.x), a.ubo.imageWidth - 1);
+        const float dx = ((k.llc_x + k.hx * u) + 0.0f) - 0.0f;
+        reinterpret_cast<float*>(col_dx)[threadIdx.x] = dx;
+        reinterpret_cast<float*>(col_xx)[threadIdx.x] = dx * dx;
     }
     if (lane < a.rows_per_wave) {  // raytrace06.comp:58,60: v and dir.y of this wave's rows (0 * u = +0)
         const float v = lean_div(static_cast<float>(row0 + lane), a.ubo.imageHeight - 1);
@@ -573,9 +573,10 @@ __global__ __launch_bounds__(256) void ch_kernel_rows<kChTwoPhase>(ChArgs a) {
         row_yy[wave][lane] = dy * dy;
     }
     __syncthreads();
+    const uint32_t c = col0 + 4u * lane;
     if (c >= a.width) return;
     const bool vec = c + 3u < a.width && a.vector_store != 0u;  // a whole, 16-byte aligned quad
-    const float4 dx4 = make_float4(dx[0], dx[1], dx[2], dx[3]), xx4 = make_float4(xx[0], xx[1], xx[2], xx[3]);
+    const float4 dx4 = col_dx[lane], xx4 = col_xx[lane];
     for (uint32_t j = 0; j < a.rows_per_wave; ++j) {
         const uint32_t row = row0 + j;
         if (row >= a.height) break;
@@ -3508,11 +3509,20 @@ hipError_t launch_ch(const ChArgs& args, hipStream_t stream) {
     // [1, 2^24] (RTIOW_DEBUG_CH_LEAN, knobs build: the exact lean kernel, for A/B and parity tests)
     auto countable = [](float v) { return v - 1.0f >= 1.0f && v - 1.0f <= 0x1p24f; };
     const bool two_phase = lean && countable(a.ubo.imageWidth) && countable(a.ubo.imageHeight) && !debug_knob("RTIOW_DEBUG_CH_LEAN");
-    // rows a wave renders: enough workgroups to fill the chip eight times over first (the reference's 800x608 frame is
-    // launch-bound: 4 rows per workgroup, 608 workgroups), then up to 16 so that the per-column values are reused
     const uint32_t tiles_x = (a.width + kChTileCols - 1u) / kChTileCols;
     uint32_t rpw = 1u;
-    while (rpw < 16u && static_cast<unsigned long long>(tiles_x) * ((a.height + 8u * rpw - 1u) / (8u * rpw)) >= 2048ull) rpw *= 2u;
+    if (two_phase) {
+        // Two-phase kernel: a wave's rows are its serial path (a row of sphere pixels is ~300 instructions) and the chip holds 2048
+        // workgroups at a time, so rows are added to a wave only while that leaves 4096 workgroups -- 8192 for the step to 16 rows.
+        // Measured (tools/ch_bandwidth.py, ms): 4096^2 with 2 / 4 / 8 rows per wave 0.0261 / 0.0247 / 0.0282; 8192^2 with 4 / 8 / 16:
+        // 0.0666 / 0.0655 / 0.074; 16384^2 at 16: 0.219.  The reference's 800 x 608: 608 workgroups of 4 rows.
+        while (rpw < 16u && static_cast<unsigned long long>(tiles_x) * ((a.height + 8u * rpw - 1u) / (8u * rpw)) >= (rpw == 8u ? 8192ull : 4096ull))
+            rpw *= 2u;
+    } else {
+        // rows a wave renders: enough workgroups to fill the chip eight times over first (the reference's 800x608 frame is
+        // launch-bound: 4 rows per workgroup, 608 workgroups), then up to 16 so that the per-column values are reused
+        while (rpw < 16u && static_cast<unsigned long long>(tiles_x) * ((a.height + 8u * rpw - 1u) / (8u * rpw)) >= 2048ull) rpw *= 2u;
+    }
     a.rows_per_wave = rpw;
     a.vector_store = (reinterpret_cast<uintptr_t>(a.dst) % 16u == 0u && a.dst_stride % 4u == 0u) ? 1u : 0u;
     a.row_blocks = (a.height + 4u * rpw - 1u) / (4u * rpw);
