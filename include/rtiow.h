@@ -190,7 +190,13 @@ int rtRender(RtContext* ctx, const RtCamera* cam, const RtParams* params, void* 
              size_t dst_pitch, int dst_is_device, void* stream);
 
 /* The reference's own call shape: 20-byte UBO in, image out
- * (RTCHAP06/main.cpp:109-124 + :313-325).  mode is RT_MODE_CH05/CH06. */
+ * (RTCHAP06/main.cpp:109-124 + :313-325).  mode is RT_MODE_CH05/CH06.
+ * The image is the shaders' byte for byte (raytrace05.comp / raytrace06.comp evaluated in IEEE float32 without contraction,
+ * imageStore to rgba8 with alpha 0, row 0 at the bottom) for EVERY UBO; how it is computed depends on the UBO only in speed:
+ * viewport and focal length within [2^-20, 2^20] in magnitude and image extents in [2, 2^24 + 1] take kernels whose roots
+ * and quotients drop range handling that cannot trigger there, and whose pixels are computed from one-ulp approximations
+ * wherever an error bound proves the stored byte the same (the exact arithmetic elsewhere); any other UBO takes the
+ * compiler's full forms.  One-row or one-column images take one lane per pixel, as the reference dispatches. */
 int rtRenderUbo(RtContext* ctx, const RtUbo5* ubo, uint32_t mode, void* dst, size_t dst_pitch,
                 int dst_is_device, void* stream);
 

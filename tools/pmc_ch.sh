@@ -10,6 +10,7 @@ export TMPDIR=/tmp
 cd /tmp
 CMD="python3 $R/tools/ch_bandwidth.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_ch -- $CMD > $O/prof_${TAG}_ch.log 2>&1
+export CH_BW_NO_CH05=1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY \
     --output-format csv -d $O/prof_${TAG}_ch_sq -- $CMD > $O/prof_${TAG}_ch_sq.log 2>&1
 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_BRANCH SQ_WAVES \

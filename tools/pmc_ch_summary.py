@@ -29,7 +29,7 @@ if ks:
     shutil.copy(ks, os.path.join(prof, f"{tag}_ch_kernel_stats.csv"))
 log = os.path.join(out, f"prof_{tag}_ch.log")
 if os.path.exists(log):
-    lines = [l for l in open(log) if l.startswith("CH06")]
+    lines = [l for l in open(log) if l.startswith("CH0")]
     open(os.path.join(prof, f"{tag}_ch_bandwidth.txt"), "w").writelines(lines)
     doc["_bandwidth_under_rocprof"] = [l.strip() for l in lines]
 json.dump(doc, open(os.path.join(prof, f"{tag}_ch_pmc.json"), "w"), indent=1, sort_keys=True)

@@ -17,3 +17,5 @@ RTIOW_LIB=$PWD/vulkan-rtiow_amd/librtiow_hip_dbg.so RTIOW_DEBUG_HIST=1 python to
 RTIOW_DEBUG_HIST=1 RTIOW_LIB=$PWD/vulkan-rtiow_amd/librtiow_hip_tl.so python tools/timeline.py 8 1 > $O/r04_timeline.txt 2>&1; grep -E "iterations after|queue 0 head|G=" $O/r04_timeline.txt | cut -c1-200
 python tools/inflight.py > $O/r04_inflight.txt 2>&1; tail -8 $O/r04_inflight.txt
 BENCH_ONE_DEVICE=1 BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 > $O/r04_bench_2rank_gloo_rehearsal_one_gpu.json 2> $O/r04_bench_2rank.err; python -c "import json; d=json.load(open('$O/r04_bench_2rank_gloo_rehearsal_one_gpu.json')); print('2-rank gloo rehearsal', d['ms_per_step'], d['config']['gathered_frame_vs_single_gpu_frame'], d['frame_check'])" || tail -5 $O/r04_bench_2rank.err
+python tools/ch_bandwidth.py 800x608 2048x2048 4096x4096 8192x8192 16384x8192 16384x16384 2> /dev/null | grep "^CH0" > $O/r04_ch_bandwidth_plain.txt; cat $O/r04_ch_bandwidth_plain.txt
+RTIOW_LIB=$PWD/vulkan-rtiow_amd/librtiow_hip_knobs.so RTIOW_DEBUG_CH_LEAN=1 python tools/ch_bandwidth.py 4096x4096 16384x8192 16384x16384 2> /dev/null | grep "^CH0" > $O/r04_ch_bandwidth_exact_lean.txt; cat $O/r04_ch_bandwidth_exact_lean.txt

@@ -442,7 +442,7 @@ DI bool ch_is_sphere(const ChConst& k, float bound, float qa) { return qa * (4 *
 // and for none when it is negative (the sphere is behind the camera: the whole frame is sky, these pixels by the exact arithmetic).
 DI uint32_t ch_sphere_two_phase(uint32_t mode, const ChConst& k, float dx, float dy, float qa) {
     if (mode == RT_MODE_CH05) return pack_rgb(255u, 0u, 0u);  // = ch_unorm8 of (1, 0, 0)
-    const float disc = k.qb * k.qb - 4 * qa * k.qc;
+    const float disc = k.qb * k.qb - qa * (4 * k.qc);  // = qb * qb - 4 * qa * qc, the product as ch_is_sphere has it (see there)
     const float t = lean_div(-k.qb - lean_sqrt(disc), 2.0f * qa);
     if (__builtin_expect(!(t > 0.0f), 0)) return ch_sky_colour<true>(lean_div(dy, lean_sqrt(qa))) | kChPhase2Flag;
     // rayAt's "origin + t * dir" adds +0 to each product in the shader; that turns a -0 into +0 and nothing else, and a zero coordinate of
