@@ -145,6 +145,46 @@ def cpu_baseline(V, sph, mat, cam, w, h, spp, depth, chunk, target_s=15.0):
     }
 
 
+def reference_shader_rates(V, torch, ctx, stream):
+    """The reference's own two compute shaders (CH05 / CH06: rtRenderUbo's path) where bytes matter -- a 16384^2
+    frame, 1 GiB, 4 bytes per pixel written once -- and at the reference's own 800 x 608: kernel time from the library's HIP events
+    (RtStats.kernel_ms), the median of launches 50 ms apart and of the second half of 32 launches back to back (the clock drops a few
+    milliseconds into a run of such launches: DESIGN 4.1).  Untimed extra.  Cross-check on the GPU: the row kernel's frame equals the
+    statement-for-statement tiled form's (RtParams.kernel = 1) at 2048 x 1024, both shaders."""
+    import statistics
+    out = {}
+    same = True
+    for mode in (V.RT_MODE_CH05, V.RT_MODE_CH06):
+        a = torch.empty((1024, 2048), dtype=torch.int32, device="cuda")
+        b = torch.empty_like(a)
+        ctx.render_device(None, V.make_params(2048, 1024, mode=mode), a.data_ptr(), 2048 * 4, stream.cuda_stream)
+        ctx.render_device(None, V.make_params(2048, 1024, mode=mode, kernel=1), b.data_ptr(), 2048 * 4, stream.cuda_stream)
+        ctx.synchronize()
+        same = same and bool(torch.equal(a, b))
+    out["row_kernel_equals_tiled_form"] = same
+    for name, mode, w, h in (("ch06_16384x16384", V.RT_MODE_CH06, 16384, 16384), ("ch05_16384x16384", V.RT_MODE_CH05, 16384, 16384),
+                             ("ch06_800x608", V.RT_MODE_CH06, 800, 608)):
+        buf = torch.empty((h, w), dtype=torch.int32, device="cuda")
+        prm = V.make_params(w, h, mode=mode)
+
+        def launch():
+            ctx.render_device(None, prm, buf.data_ptr(), w * 4, stream.cuda_stream)
+            return ctx.stats().kernel_ms
+
+        launch(), launch()
+        spaced = []
+        for _ in range(8):
+            time.sleep(0.05)
+            spaced.append(launch())
+        time.sleep(0.2)
+        run = [launch() for _ in range(32)]
+        ms, sus = statistics.median(spaced), statistics.median(run[16:])
+        out[name] = {"kernel_ms": ms, "gb_per_s": w * h * 4 / ms / 1e6, "hbm_frac": w * h * 4 / ms / 1e6 / HBM_PEAK_GBS,
+                     "sustained_kernel_ms": sus, "sustained_gb_per_s": w * h * 4 / sus / 1e6}
+        del buf
+    return out
+
+
 def cold_and_moving_frames(V, torch, dev, device_id, sph, mat, cam, prm, w, h, timed_frame, warm_ctx, stream, scratch):
     """Outside the timed region, N = 1: what the steady state of a static view leaves out.
     first_frame_ms: a FRESH context's first frame of the same view -- scene just uploaded, no chunk order yet, counters set by a
@@ -548,6 +588,8 @@ def run(args, np, torch, dist, V, D, world, rank, local_rank, backend, dev):
         if world == 1 and quick and scene == "cover":
             out["config"].update(cold_and_moving_frames(V, torch, dev, local_rank, sph, mat, cam, prm, w, h, frame, ctx, streams[0],
                                                         locals_[0]))
+        if world == 1 and quick:
+            out["config"]["reference_shaders"] = reference_shader_rates(V, torch, ctx, streams[0])
         clock = ctx_clock_mhz
         out["roofline"]["shader_clock_mhz"] = clock or None
         out["roofline"]["peak_at_held_clock"] = FP32_VALU_PEAK_TFLOPS * clock / 2400.0 if clock else None
