@@ -460,14 +460,15 @@ def test_ch_sky_table_is_what_its_generator_derives():
     """csrc/rtiow_ch_sky_table.h -- the sky colour of raytrace06.comp:45-47 as a step function of normalize(dir).y, on which the first
     phase of ch_kernel_rows' two-phase pixels rests -- is exactly what tools/gen_ch_sky_table.py generates: the script evaluates its
     float32 restatement of the shader's sky arithmetic on all 25 million values unit_y + 1 can take, collects the 280 floats where the
-    colour changes, and checks on the host that every float within the guard band of a step is sent to the exact second phase and that
-    the table's colour holds for every float within the guard band of an un-flagged one.  (On the GPU, tests/test_gpu_ch_two_phase.py
+    colour changes, and proves on the host -- interval by interval, for every float the kernel's index can send to each bucket -- that
+    every float within the guard band of a step is sent to the exact second phase and that the table's colour holds for every float
+    within the guard band of an un-flagged one.  (On the GPU, tests/test_gpu_ch_two_phase.py
     finds the same 280 floats by evaluating the kernel's own code on all 2.1 billion floats of [-1, 1].)"""
     import subprocess
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_ch_sky_table.py"), "--check"], capture_output=True, text=True,
                          timeout=600)
     assert res.returncode == 0, res.stdout[-500:] + res.stderr[-1500:]
-    assert "280 changes in 179 zones" in res.stdout, res.stdout
+    assert "280 changes in 179 zones" in res.stdout and "691 un-flagged intervals proven" in res.stdout, res.stdout
 
 
 def test_ch_sky_steps_follow_the_quantiser():

@@ -18,7 +18,9 @@ Table entry for bucket i = trunc(fma(unit_y', 256, 256)), i in 0..512:  { lo, hi
 with lo = first - G, hi = last + G rounded outwards and G = 2^-21 >= the distance between the fast phase's unit_y' =
 dy * v_rsq_f32(qa) and the shader's RN(dy / RN(sqrt(qa))) (2.5 * 2^-23 at most: DESIGN section 4.1).  A bucket without a zone has
 lo = hi = +inf.  The script refuses to write a table in which a bucket (widened by 2^-20 for the rounding of the index and by G)
-meets two zones.
+meets two zones, and before it writes anything it proves the table (prove(): for every bucket, the exact interval of floats the kernel's
+index sends there, and on each un-flagged part of it no step of F within G and the right colour -- 691 intervals, every float covered)
+and spot-checks it against the arithmetic itself (verify(): seven million floats).
 
     python tools/gen_ch_sky_table.py            # writes the header
     python tools/gen_ch_sky_table.py --check    # regenerates and compares with the committed header (tests/test_host_logic.py)
@@ -166,6 +168,54 @@ def verify(table, zones, steps):
     return int(flagged.sum()), ys.size
 
 
+def prove(table, steps):
+    """The same claim as verify(), not on samples but for EVERY float: for bucket i, the floats y1 the kernel's index sends there form an
+    interval [a_i, b_i] (the index is monotone in y1: found by bisection on the emulated fma + truncation); the first phase answers
+    `below` on [a_i, lo) and `above` on (hi, b_i] -- and F, whose every change is in `steps` (the scan of H is exhaustive), must be that
+    one colour on the whole of [a_i - G, lo + G) resp. (hi - G, b_i + G]: no step inside, and the colour right."""
+    step_y = np.array([float(s[0]) for s in steps])      # F changes AT these floats (first float of the new colour)
+    after = [s[2] for s in steps]
+    first_colour = steps[0][1]
+
+    def colour_on(x0, x1):
+        """F's colour on the real interval [x0, x1] if it is constant there, else None (a step T lies in it when x0 < T <= x1)."""
+        k0, k1 = np.searchsorted(step_y, x0, side="right"), np.searchsorted(step_y, x1, side="right")
+        if k0 != k1:
+            return None
+        return after[k0 - 1] if k0 > 0 else first_colour
+
+    klo, khi = int(float_to_key(f32(-1.0 - 2.0 ** -20))), int(float_to_key(f32(1.0 + 2.0 ** -20)))
+
+    def first_key_with_bucket_at_least(i):
+        lo, hi = klo - 1, khi + 1  # bucket(lo) < i <= bucket(hi) (sentinels)
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            if int(bucket_of(key_to_float(mid))) >= i:
+                hi = mid
+            else:
+                lo = mid
+        return hi
+
+    starts = [first_key_with_bucket_at_least(i) for i in range(N_BUCKETS + 1)]
+    assert starts[0] == klo and starts[N_BUCKETS] == khi + 1, "the kernel's unit_y' (|y1| <= 1 + 2^-21) stays inside the table"
+    checked = 0
+    for i in range(N_BUCKETS):
+        if starts[i + 1] == starts[i]:
+            continue
+        a_i, b_i = float(key_to_float(starts[i])), float(key_to_float(starts[i + 1] - 1))
+        lo, hi, below, above = table[i]
+        lo, hi = float(lo), float(hi)
+        if a_i < lo:   # floats of the bucket below lo: [a_i, min(b_i, pred(lo))]
+            top = min(b_i, float(np.nextafter(f32(lo), f32(-4)))) if np.isfinite(lo) else b_i
+            assert colour_on(a_i - GUARD, top + GUARD) == below, (i, "below")
+            checked += 1
+        if np.isfinite(hi) and b_i > hi:  # floats of the bucket above hi: [max(a_i, succ(hi)), b_i]
+            bottom = max(a_i, float(np.nextafter(f32(hi), f32(4))))
+            assert colour_on(bottom - GUARD, b_i + GUARD) == above, (i, "above")
+            checked += 1
+    return checked
+
+
 def render(table, zones):
     out = ["// GENERATED by tools/gen_ch_sky_table.py -- do not edit.  The sky colour of raytrace06.comp:45-47 as a step function of",
            "// normalize(dir).y: entry i = { lo, hi, colour below lo, colour above hi } for bucket i = trunc(fma(unit_y, 256, 256)); between lo",
@@ -184,11 +234,13 @@ def render(table, zones):
 def main():
     table, zones, steps = build()
     flagged, n = verify(table, zones, steps)
+    intervals = prove(table, steps)
     text = render(table, zones)
     if "--check" in sys.argv:
         if open(HEADER).read() != text:
             raise SystemExit("rtiow_ch_sky_table.h differs from what tools/gen_ch_sky_table.py generates")
-        print(f"ok: {len(steps)} changes in {len(zones)} zones; header up to date; {flagged} of {n} sample floats take the second phase")
+        print(f"ok: {len(steps)} changes in {len(zones)} zones; header up to date; {intervals} un-flagged intervals proven constant within the "
+              f"guard band; {flagged} of {n} sample floats take the second phase")
         return
     with open(HEADER, "w") as f:
         f.write(text)
