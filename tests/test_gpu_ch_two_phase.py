@@ -139,6 +139,22 @@ def test_normal_two_phase_equals_the_exact_normal_colour(gpu_ctx):
     second = (two & PHASE2) != 0
     assert second[: n // 2].mean() > 0.02            # the aimed ones: 2^-13 of 2^-12 either side, and the other two channels
     assert 1e-4 < second[n // 2:].mean() < 3e-3      # the random ones: ~ 3 channels x 2 x 2^-13 = 7e-4
+    # the distance the guard band D = 2^-13 covers, operation by operation on the GPU: the shader's y = (0.5 (v_c / sqrt(d) + 1)) 255 + 0.5
+    # against phase 1's fma(v_c * v_rsq_f32(d), 127.5, 128) -- bound 7.7e-5, D = 1.22e-4
+    zero = np.zeros(n, f32)
+    one = np.ones(n, f32)
+    mul = lambda a, b: _arith(gpu_ctx, 3, a, b)
+    add = lambda a, b: _arith(gpu_ctx, 4, a, b)
+    d = add(add(mul(v[:, 0], v[:, 0]), mul(v[:, 1], v[:, 1])), mul(v[:, 2], v[:, 2]))  # gdot(v, v)
+    l = _arith(gpu_ctx, 8, d)
+    inv = _arith(gpu_ctx, 10, d)
+    worst = 0.0
+    for c in range(3):
+        nrm = _arith(gpu_ctx, 9, v[:, c], l)
+        y = add(mul(mul(np.full(n, 0.5, f32), add(nrm, one)), np.full(n, 255.0, f32)), np.full(n, 0.5, f32))
+        y1 = _arith(gpu_ctx, 0, mul(v[:, c], inv), np.full(n, 127.5, f32), np.full(n, 128.0, f32))
+        worst = max(worst, float(np.abs(y.astype(np.float64) - y1.astype(np.float64)).max()))
+    assert worst <= 7.7e-5 < 2.0 ** -13, worst
 
 
 @pytest.mark.parametrize("mode", [V.RT_MODE_CH05, V.RT_MODE_CH06])
