@@ -380,7 +380,7 @@ DI uint32_t ch_pixel(uint32_t mode, const ChConst& k, float dx, float xx, float 
 //     all 25 million values unit_y + 1 can take, and writes rtiow_ch_sky_table.h: per bucket of 1/256 of unit_y one zone [lo, hi]
 //     widened by G = 2^-21 either side and the colours below and above it.  Phase 1: y1 = dy * v_rsq_f32(qa).  With r = dy / sqrt(qa)
 //     (|r| <= 1 + 2^-22: qa contains dy * dy) and h = 2^-24, unit_y = r (1 + e2) / (1 + e1) with |e1|, |e2| <= h lies within 2 h |r|
-//     (1 + h) of r, and y1 = r (1 + e6)(1 + e7) with |e6| <= 2 h (one ulp: tests/test_gpu_parity.py measures it on every float of a
+//     (1 + h) of r, and y1 = r (1 + e6)(1 + e7) with |e6| <= 2 h (one ulp: tests/test_gpu_ch_two_phase.py measures it on every float of a
 //     binade pair), |e7| <= h within 3 h |r| (1 + h): |y1 - unit_y| < 5.01 h < 0.63 G.  So y1 < lo means unit_y lies below the zone's
 //     first step, y1 > hi means it lies at or above the last, and F(unit_y) is the table's colour; anything else is computed.
 //   * SPHERE (raytrace06's normal colour).  t is exact as before (it is multiplied into three coordinates, and its error would be
