@@ -589,7 +589,10 @@ def run(args, np, torch, dist, V, D, world, rank, local_rank, backend, dev):
             out["config"].update(cold_and_moving_frames(V, torch, dev, local_rank, sph, mat, cam, prm, w, h, frame, ctx, streams[0],
                                                         locals_[0]))
         if world == 1 and quick:
-            out["config"]["reference_shaders"] = reference_shader_rates(V, torch, ctx, streams[0])
+            try:  # (an untimed extra on a 1 GiB frame: it must not cost the run its line)
+                out["config"]["reference_shaders"] = reference_shader_rates(V, torch, ctx, streams[0])
+            except Exception as e:  # noqa: BLE001
+                out["config"]["reference_shaders"] = {"error": f"{type(e).__name__}: {e}"}
         clock = ctx_clock_mhz
         out["roofline"]["shader_clock_mhz"] = clock or None
         out["roofline"]["peak_at_held_clock"] = FP32_VALU_PEAK_TFLOPS * clock / 2400.0 if clock else None
