@@ -1,0 +1,73 @@
+// Exhaustive comparison (every positive finite float) of short correctly-rounded-square-root candidates against the lean form the
+// kernels use (lean_sqrt: v_sqrt_f32 + the residual check of its two neighbours, 10 instructions) and against sqrtf.
+//   hipcc -O3 -ffp-contract=off --offload-arch=gfx950 -o sqrt_scan tools/sqrt_scan.hip && ./sqrt_scan
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#define DI __device__ __forceinline__
+DI float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+DI float lean_sqrt(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = fma_(-s_dn, s, x), r_up = fma_(-s_up, s, x);
+    const float r = (0.0f >= r_dn) ? s_dn : s;
+    return (0.0f < r_up) ? s_up : r;
+}
+DI float cand_a(float x) {  // rsq, one Newton step on the root
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y, h = 0.5f * y;
+    return fma_(fma_(-g, g, x), h, g);
+}
+DI float cand_b(float x) {  // ... and a second one
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y, h = 0.5f * y;
+    const float s = fma_(fma_(-g, g, x), h, g);
+    return fma_(fma_(-s, s, x), h, s);
+}
+DI float cand_c(float x) {  // Markstein: refine h and g together, then the residual step
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y, h = 0.5f * y;
+    const float e = fma_(-h, g, 0.5f);
+    const float h1 = fma_(h, e, h), g1 = fma_(g, e, g);
+    return fma_(fma_(-g1, g1, x), h1, g1);
+}
+DI float cand_d(float x) {  // v_sqrt_f32 and one residual step with h = 0.5 * rsq
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float h = 0.5f * __builtin_amdgcn_rsqf(x);
+    return fma_(fma_(-s, s, x), h, s);
+}
+DI float cand_e(float x) {  // cand_a with the operand kept away from zero (x = 0 -> 0)
+    const float y = __builtin_amdgcn_rsqf(__builtin_fmaxf(x, 0x1p-126f));
+    const float g = x * y, h = 0.5f * y;
+    return fma_(fma_(-g, g, x), h, g);
+}
+__global__ void scan(uint32_t lo, unsigned long long n, unsigned long long* bad, uint32_t* first) {
+    const unsigned long long i = blockIdx.x * 256ull + threadIdx.x;
+    if (i >= n) return;
+    const float x = __uint_as_float(lo + static_cast<uint32_t>(i));
+    const float want = __builtin_sqrtf(x);
+    const float got[6] = {lean_sqrt(x), cand_a(x), cand_b(x), cand_c(x), cand_d(x), cand_e(x)};
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        if (__float_as_uint(got[k]) != __float_as_uint(want)) {
+            const unsigned long long at = atomicAdd(&bad[k], 1ull);
+            if (at < 4) first[k * 4 + at] = __float_as_uint(x);
+        }
+}
+int main() {
+    unsigned long long* bad; uint32_t* first;
+    hipMallocManaged(&bad, 6 * 8); hipMallocManaged(&first, 24 * 4);
+    const char* names[6] = {"lean_sqrt", "rsq+1 step", "rsq+2 steps", "markstein", "sqrt+1 step", "rsq(max)+1 step"};
+    // ranges: [2^-96, max finite] (the lean forms' domain), and the rest of the normals below
+    const uint32_t edges[4] = {0x00800000u, 0x0F800000u /* 2^-96 */, 0x7F800000u, 0};
+    for (int r = 0; r < 2; ++r) {
+        for (int k = 0; k < 6; ++k) bad[k] = 0;
+        for (int k = 0; k < 24; ++k) first[k] = 0;
+        const unsigned long long n = edges[r + 1] - edges[r];
+        hipLaunchKernelGGL(scan, dim3((n + 255) / 256), dim3(256), 0, 0, edges[r], n, bad, first);
+        hipDeviceSynchronize();
+        printf("floats [%08x, %08x): %llu\n", edges[r], edges[r + 1], n);
+        for (int k = 0; k < 6; ++k) printf("  %-18s mismatches vs sqrtf: %llu   first: %08x %08x %08x %08x\n", names[k], bad[k], first[4*k], first[4*k+1], first[4*k+2], first[4*k+3]);
+    }
+    return 0;
+}

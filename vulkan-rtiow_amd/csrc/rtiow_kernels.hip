@@ -168,6 +168,19 @@ DI float lean_div(float a, float b) {
     const float q1 = fma_(fma_(-b, q0, a), r1, q0);
     return fma_(fma_(-b, q1, a), r1, q1);
 }
+// The correctly rounded square root in SIX instructions: v_rsq_f32 and one Newton step on the root, g = x y, h = y / 2, s = g + (x - g g) h.
+// That the step lands on RN(sqrt(x)) is not a theorem about one-ulp starting values -- it is a fact about this GPU's v_rsq_f32, and a
+// function of ONE float can be checked on every float: rtSelfTestSqrtScan evaluates it on all 1 879 048 192 floats of [2^-96, 2^128)
+// against sqrtf -- no mismatch (tests/test_gpu_parity.py; tools/sqrt_scan.hip tried five such forms, all exact there, this is the
+// shortest).  The operand is kept away from zero by one v_max_f32, so that +0 gives +0 and -0 gives -0 (y = 2^63, g = +-0, s = +-0);
+// NaN gives NaN (g is NaN).  NOT for negative operands (a negative number comes out where sqrtf gives NaN) nor +inf (NaN): the one
+// site whose operand can be negative keeps lean_sqrt (psqrt_signed).  Below 2^-96 the residual loses bits to underflow and the result
+// may be an ulp off, as lean_sqrt's may: it stays within a few ulps of sqrt(x), which is all the ray-sphere tests' argument below needs.
+DI float newton_sqrt(float x) {
+    const float y = __builtin_amdgcn_rsqf(__builtin_fmaxf(x, 0x1p-126f));
+    const float g = x * y, h = 0.5f * y;
+    return fma_(fma_(-g, g, x), h, g);
+}
 
 // PATH mode takes the same lean forms wherever their precondition holds for EVERY input the kernels can see (psqrt, pdiv: 10 and 8
 // instructions instead of 16 and 12; a segment takes a dozen square roots).  Site by site:
@@ -187,11 +200,15 @@ DI float lean_div(float a, float b) {
 //     would have to; such a sample may differ from the oracle in its last bits.  unit3 of a CAMERA ray keeps hipcc's forms: its length is
 //     whatever the caller's camera makes it;
 //   * resolve_pixel: scale * sum with scale >= 2^-48 and sum an integer: 0 or >= 2^-48.
-// -DRTIOW_LEAN_PATH=0: hipcc's forms everywhere (A/B and a parity check of the above: the frames are the same).
+// Late in round 4 the square roots became newton_sqrt (six instructions, above) at every site but the dielectric's 1 - cos^2, the only
+// operand that can be negative: for x == 0 or x >= 2^-96 it IS sqrtf(x), like lean_sqrt, so every argument above stands; the lock-step
+// test of the large spheres takes the root of any discriminant and reads it only when the discriminant is >= +0.
+// -DRTIOW_LEAN_PATH=0: hipcc's forms everywhere; =1: lean_sqrt everywhere (A/B and parity checks of the above: the frames are the same).
 #ifndef RTIOW_LEAN_PATH
-#define RTIOW_LEAN_PATH 1
+#define RTIOW_LEAN_PATH 2
 #endif
-DI float psqrt(float x) { return RTIOW_LEAN_PATH ? lean_sqrt(x) : __builtin_sqrtf(x); }
+DI float psqrt(float x) { return RTIOW_LEAN_PATH == 2 ? newton_sqrt(x) : RTIOW_LEAN_PATH ? lean_sqrt(x) : __builtin_sqrtf(x); }
+DI float psqrt_signed(float x) { return RTIOW_LEAN_PATH ? lean_sqrt(x) : __builtin_sqrtf(x); }  // NaN for a negative operand, as sqrtf
 DI float pdiv(float a, float b) { return RTIOW_LEAN_PATH ? lean_div(a, b) : a / b; }
 
 #ifndef RTIOW_TU_PART
@@ -443,7 +460,7 @@ DI bool ch_is_sphere(const ChConst& k, float bound, float qa) { return qa * (4 *
 DI uint32_t ch_sphere_two_phase(uint32_t mode, const ChConst& k, float dx, float dy, float qa) {
     if (mode == RT_MODE_CH05) return pack_rgb(255u, 0u, 0u);  // = ch_unorm8 of (1, 0, 0)
     const float disc = k.qb * k.qb - qa * (4 * k.qc);  // = qb * qb - 4 * qa * qc, the product as ch_is_sphere has it (see there)
-    const float t = lean_div(-k.qb - lean_sqrt(disc), 2.0f * qa);
+    const float t = lean_div(-k.qb - newton_sqrt(disc), 2.0f * qa);  // (disc is +0 or at least 2^-63 here: the exact root)
     if (__builtin_expect(!(t > 0.0f), 0)) return ch_sky_colour<true>(lean_div(dy, lean_sqrt(qa))) | kChPhase2Flag;
     // rayAt's "origin + t * dir" adds +0 to each product in the shader; that turns a -0 into +0 and nothing else, and a zero coordinate of
     // either sign squares to +0 and divides to a zero that is 0.5 two operations later: the additions are left out (the second phase is
@@ -713,7 +730,7 @@ DI bool scatter(f3 ctr, const ShadeRec& m, float s, Path& p) {
         const float ratio = front ? (RTIOW_GLASS_HOST ? m.albedo[0] : 1.0f / m.param) : m.param;  // 1 / ior : ior
         const float nd = -dot3(p.du, n);
         const float cosv = (nd < 1.0f) ? nd : 1.0f;
-        const float sinv = psqrt(fma_(-cosv, cosv, 1.0f));
+        const float sinv = psqrt_signed(fma_(-cosv, cosv, 1.0f));  // (cosv < -1 by an ulp: negative, NaN as in the oracle)
         bool reflect = ratio * sinv > 1.0f;
         if (!reflect) {  // Schlick; (1-cos)^5 by repeated multiply, never powf
             float r0 = RTIOW_GLASS_HOST ? (front ? m.albedo[1] : m.albedo[2]) : (1.0f - ratio) / (1.0f + ratio);
@@ -3360,6 +3377,7 @@ __global__ void arith_kernel(uint32_t op, const float* a, const float* b, const 
         case 13: r = __uint_as_float(ch_sky_colour<true>(a[i])); break;                                // F(unit_y)
         case 14: r = __uint_as_float(ch_normal_two_phase(mk(a[i], b[i], c[i]))); break;                // the normal colour of v
         case 15: { const f3 v = mk(a[i], b[i], c[i]); r = __uint_as_float(ch_normal_colour<true>(v, lean_sqrt(gdot(v, v)))); break; }
+        case 17: r = newton_sqrt(a[i]); break;  // the six-instruction square root of the PATH kernels and the two-phase CH pixels
         case 16: { bool second; const uint32_t col = ch_sky_phase1(reinterpret_cast<const uint4*>(ch_sky_table_words), a[i], second); r = __uint_as_float(second ? kChPhase2Flag : col); break; }  // the table alone
         default: break;
     }
@@ -3381,6 +3399,18 @@ __global__ __launch_bounds__(256) void ch_sky_steps_kernel(long long key_lo, uns
         if (at < cap) out[at] = RtChSkyStep{y, before, after};
     }
 }
+// newton_sqrt against sqrtf on every float of [lo, hi] (bit patterns of positive floats, ascending): the number of floats on which the
+// two differ, and the first few of them.  rtSelfTestSqrtScan; the proof of newton_sqrt is this kernel's zero over [2^-96, 2^128).
+__global__ __launch_bounds__(256) void sqrt_scan_kernel(uint32_t lo_bits, unsigned long long n, unsigned long long* bad, uint32_t* first, uint32_t cap) {
+    const unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * 256ull + threadIdx.x;
+    if (i >= n) return;
+    const float x = __uint_as_float(lo_bits + static_cast<uint32_t>(i));
+    if (__float_as_uint(newton_sqrt(x)) != __float_as_uint(__builtin_sqrtf(x))) {
+        const unsigned long long at = atomicAdd(bad, 1ull);
+        if (at < cap) first[at] = __float_as_uint(x);
+    }
+}
+
 // ============================================================================
 // chunk order for the next frame (cost-ordered dequeue): one workgroup, counting sort on 1024 cost classes
 // ============================================================================
@@ -3792,6 +3822,16 @@ hipError_t launch_ch_sky_steps(float lo, float hi, RtChSkyStep* out, uint32_t ca
     if (k1 < k0) return hipErrorInvalidValue;
     const unsigned long long n = static_cast<unsigned long long>(k1 - k0) + 1ull;
     hipLaunchKernelGGL(ch_sky_steps_kernel, dim3(static_cast<uint32_t>((n + 255ull) / 256ull)), dim3(256), 0, stream, k0, n, out, cap, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_sqrt_scan(float lo, float hi, unsigned long long* bad, uint32_t* first, uint32_t cap, hipStream_t stream) {
+    uint32_t b0, b1;
+    std::memcpy(&b0, &lo, 4);
+    std::memcpy(&b1, &hi, 4);
+    if ((b0 | b1) & 0x80000000u || b1 < b0) return hipErrorInvalidValue;  // positive floats, ascending
+    const unsigned long long n = static_cast<unsigned long long>(b1 - b0) + 1ull;
+    hipLaunchKernelGGL(sqrt_scan_kernel, dim3(static_cast<uint32_t>((n + 255ull) / 256ull)), dim3(256), 0, stream, b0, n, bad, first, cap);
     return hipGetLastError();
 }
 
