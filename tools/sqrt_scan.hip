@@ -41,6 +41,40 @@ DI float cand_e(float x) {  // cand_a with the operand kept away from zero (x = 
     const float g = x * y, h = 0.5f * y;
     return fma_(fma_(-g, g, x), h, g);
 }
+DI float lean_div(float a, float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float r1 = fma_(fma_(-b, r0, 1.0f), r0, r0);
+    const float q0 = a * r1;
+    const float q1 = fma_(fma_(-b, q0, a), r1, q0);
+    return fma_(fma_(-b, q1, a), r1, q1);
+}
+// k = RN(1 / RN(sqrt(x))) -- unit3_scattered's factor -- from the same v_rsq_f32: the exact root, then Newton steps on the reciprocal
+DI void inv_root_cands(float x, float out[4]) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y, h = 0.5f * y;
+    const float s = fma_(fma_(-g, g, x), h, g);
+    const float r1 = fma_(fma_(-s, y, 1.0f), y, y);
+    const float q1 = fma_(fma_(-s, r1, 1.0f), r1, r1);
+    const float q2 = fma_(fma_(-s, q1, 1.0f), r1, q1);
+    const float r1b = fma_(fma_(-s, y, 1.0f), y, y);
+    const float q1b = fma_(fma_(-s, r1b, 1.0f), y, r1b);  // second step with y instead of r1 as the slope
+    out[0] = r1; out[1] = q1; out[2] = q2; out[3] = q1b;
+}
+__global__ void scan_inv(uint32_t lo, unsigned long long n, unsigned long long* bad, uint32_t* first) {
+    const unsigned long long i = blockIdx.x * 256ull + threadIdx.x;
+    if (i >= n) return;
+    const float x = __uint_as_float(lo + static_cast<uint32_t>(i));
+    const float want = 1.0f / __builtin_sqrtf(x), lean = lean_div(1.0f, lean_sqrt(x));
+    float got[5];
+    inv_root_cands(x, got);
+    got[4] = lean;
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        if (__float_as_uint(got[k]) != __float_as_uint(want)) {
+            const unsigned long long at = atomicAdd(&bad[k], 1ull);
+            if (at < 4) first[k * 4 + at] = __float_as_uint(x);
+        }
+}
 __global__ void scan(uint32_t lo, unsigned long long n, unsigned long long* bad, uint32_t* first) {
     const unsigned long long i = blockIdx.x * 256ull + threadIdx.x;
     if (i >= n) return;
@@ -68,6 +102,17 @@ int main() {
         hipDeviceSynchronize();
         printf("floats [%08x, %08x): %llu\n", edges[r], edges[r + 1], n);
         for (int k = 0; k < 6; ++k) printf("  %-18s mismatches vs sqrtf: %llu   first: %08x %08x %08x %08x\n", names[k], bad[k], first[4*k], first[4*k+1], first[4*k+2], first[4*k+3]);
+    }
+    {   // the reciprocal root over unit3_scattered's domain and well beyond: [2^-64, 2^64]
+        const char* inames[5] = {"root + 1 step", "root + 2 steps", "root + 3 steps", "root + 2 steps (slope y)", "lean_div(1, lean_sqrt)"};
+        for (int k = 0; k < 6; ++k) bad[k] = 0;
+        for (int k = 0; k < 24; ++k) first[k] = 0;
+        const uint32_t lo = 0x1F800000u /* 2^-64 */, hi = 0x5F800000u /* 2^64 */;
+        const unsigned long long n = hi - lo;
+        hipLaunchKernelGGL(scan_inv, dim3((n + 255) / 256), dim3(256), 0, 0, lo, n, bad, first);
+        hipDeviceSynchronize();
+        printf("1 / sqrt(x), floats [2^-64, 2^64): %llu\n", n);
+        for (int k = 0; k < 5; ++k) printf("  %-26s mismatches vs 1.0f / sqrtf(x): %llu   first: %08x %08x\n", inames[k], bad[k], first[4*k], first[4*k+1]);
     }
     return 0;
 }
