@@ -230,7 +230,7 @@ int rtGetLastKernel(RtContext* ctx, uint32_t* kernel_out);
  * a single operation.  Ops 10-16: the pieces of the two-phase CH05/CH06 pixels (results are bit patterns, bit 31 set when
  * the exact second phase ran): 10 v_rsq_f32(a); 11 / 12 the sky colour of (dy = a, dot(dir, dir) = b), two-phase / exact;
  * 13 the sky colour of normalize(dir).y = a; 14 / 15 the normal colour of v = (a, b, c), two-phase / exact; 16 the sky
- * table's answer for a alone; 17 the kernels' six-instruction square root (rtSelfTestSqrtScan).  No reference counterpart. */
+ * table's answer for a alone; 17 / 18 the kernels' six-instruction square root / three-instruction reciprocal (rtSelfTestUnaryScan).  No reference counterpart. */
 int rtSelfTestArith(RtContext* ctx, uint32_t op, const float* a, const float* b, const float* c,
                     float* out, uint32_t n);
 
@@ -245,12 +245,13 @@ typedef struct RtChSkyStep {
 } RtChSkyStep;
 int rtSelfTestChSkySteps(RtContext* ctx, float lo, float hi, RtChSkyStep* out, uint32_t cap, uint32_t* count);
 
-/* The kernels take square roots by v_rsq_f32 and one Newton step (six instructions; rtSelfTestArith op 17).  That this is
- * sqrtf(x) is a property of the GPU's v_rsq_f32, checkable because the function has ONE float argument: this call
- * evaluates both on every float of [lo, hi] (0 <= lo <= hi finite) on the GPU and returns the number of floats on which
- * they differ, the bit patterns of the first `cap` of them in `first`.  The tests run it over [2^-96, FLT_MAX]: zero.
- * Diagnostic. */
-int rtSelfTestSqrtScan(RtContext* ctx, float lo, float hi, uint64_t* mismatches, uint32_t* first, uint32_t cap);
+/* The kernels take square roots by v_rsq_f32 and one Newton step (six instructions; rtSelfTestArith op 17) and their one
+ * reciprocal by v_rcp_f32 and one Newton step (three; op 18).  That these are sqrtf(x) and 1.0f / x is a property of the
+ * GPU's two instructions, checkable because each function has ONE float argument: this call evaluates the short form
+ * (fn 0: the square root, fn 1: the reciprocal) and the compiler's on every float of [lo, hi] (0 <= lo <= hi finite) on
+ * the GPU and returns the number of floats on which they differ, the bit patterns of the first `cap` of them in `first`.
+ * The tests run it over [2^-96, FLT_MAX] and [2^-64, 2^64]: zero.  Diagnostic. */
+int rtSelfTestUnaryScan(RtContext* ctx, uint32_t fn, float lo, float hi, uint64_t* mismatches, uint32_t* first, uint32_t cap);
 
 /* ---- several GPUs of one node, one process ---------------------------------------------------
  * The reference drives exactly one device (RTCHAP06/Vulkan.cpp:87-97; one queue family by assert,

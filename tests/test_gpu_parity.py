@@ -174,12 +174,15 @@ def test_ch_lean_roots_and_quotients_equal_the_full_forms_and_the_oracle(gpu_ctx
         assert np.array_equal(lean, want), (what, _diff(lean, want))
 
 
-def test_the_six_instruction_square_root_is_sqrtf_on_every_float(gpu_ctx):
+def test_the_short_square_root_and_reciprocal_are_the_compilers_on_every_float(gpu_ctx):
     """The kernels' square root (newton_sqrt: v_rsq_f32 and one Newton step, six instructions instead of the compiler's sixteen) is a
     function of one float, so its claim -- equal to sqrtf for x == 0 and every x in [2^-96, FLT_MAX] -- is checked on EVERY such float:
-    1 879 048 192 of them on the GPU (rtSelfTestSqrtScan), zero mismatches; sqrtf itself (op 2) and the form (op 17) against the host's
+    1 879 048 192 of them on the GPU (rtSelfTestUnaryScan), zero mismatches -- and likewise the reciprocal (newton_rcp: v_rcp_f32 and one
+    Newton step, three instructions instead of twelve) against 1.0f / x on the 1 073 741 824 floats of [2^-64, 2^64); sqrtf itself (op 2) and the form (op 17) against the host's
     correctly rounded root on samples; and the special operands it is used with."""
-    bad, first = gpu_ctx.selftest_sqrt_scan(2.0 ** -96, float(np.finfo(np.float32).max))
+    bad, first = gpu_ctx.selftest_unary_scan(0, 2.0 ** -96, float(np.finfo(np.float32).max))
+    assert bad == 0, (bad, first)
+    bad, first = gpu_ctx.selftest_unary_scan(1, 2.0 ** -64, 2.0 ** 64)
     assert bad == 0, (bad, first)
     rng = np.random.default_rng(17)
     x = np.concatenate([(rng.uniform(1.0, 2.0, 1 << 18) * 2.0 ** rng.integers(-96, 127, 1 << 18)).astype(np.float32),
@@ -190,6 +193,9 @@ def test_the_six_instruction_square_root_is_sqrtf_on_every_float(gpu_ctx):
     assert np.array_equal(got.view(np.uint32), full.view(np.uint32))
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert np.isnan(gpu_ctx.selftest_arith(17, np.array([np.nan], np.float32), z[:1], z[:1])[0])
+    s = (rng.uniform(1.0, 2.0, 1 << 18) * 2.0 ** rng.integers(-64, 64, 1 << 18)).astype(np.float32)
+    zs = np.zeros_like(s)
+    assert np.array_equal(gpu_ctx.selftest_arith(18, s, zs, zs).view(np.uint32), (np.float32(1.0) / s).view(np.uint32))
     # below 2^-96 it may be an ulp off (the residual underflows), like the compiler's core without its rescaling -- but never far off:
     # the ray-sphere tests' argument needs a value within a few ulps of the root there
     tiny = (rng.uniform(1.0, 2.0, 1 << 16) * 2.0 ** rng.integers(-126, -96, 1 << 16)).astype(np.float32)

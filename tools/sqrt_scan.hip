@@ -75,6 +75,24 @@ __global__ void scan_inv(uint32_t lo, unsigned long long n, unsigned long long* 
             if (at < 4) first[k * 4 + at] = __float_as_uint(x);
         }
 }
+// RN(1 / s) for a float s: v_rcp_f32 and Newton steps (the compiler's core, lean_div(1, s), takes 8 instructions)
+__global__ void scan_rcp(uint32_t lo, unsigned long long n, unsigned long long* bad, uint32_t* first) {
+    const unsigned long long i = blockIdx.x * 256ull + threadIdx.x;
+    if (i >= n) return;
+    const float s = __uint_as_float(lo + static_cast<uint32_t>(i));
+    const float want = 1.0f / s;
+    const float r0 = __builtin_amdgcn_rcpf(s);
+    const float r1 = fma_(fma_(-s, r0, 1.0f), r0, r0);
+    const float r2 = fma_(fma_(-s, r1, 1.0f), r1, r1);
+    const float r2b = fma_(fma_(-s, r1, 1.0f), r0, r1);
+    const float got[5] = {r0, r1, r2, r2b, lean_div(1.0f, s)};
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        if (__float_as_uint(got[k]) != __float_as_uint(want)) {
+            const unsigned long long at = atomicAdd(&bad[k], 1ull);
+            if (at < 4) first[k * 4 + at] = __float_as_uint(s);
+        }
+}
 __global__ void scan(uint32_t lo, unsigned long long n, unsigned long long* bad, uint32_t* first) {
     const unsigned long long i = blockIdx.x * 256ull + threadIdx.x;
     if (i >= n) return;
@@ -113,6 +131,17 @@ int main() {
         hipDeviceSynchronize();
         printf("1 / sqrt(x), floats [2^-64, 2^64): %llu\n", n);
         for (int k = 0; k < 5; ++k) printf("  %-26s mismatches vs 1.0f / sqrtf(x): %llu   first: %08x %08x\n", inames[k], bad[k], first[4*k], first[4*k+1]);
+    }
+    {   // the reciprocal of a float in [2^-64, 2^64)
+        const char* rnames[5] = {"v_rcp_f32", "rcp + 1 step", "rcp + 2 steps", "rcp + 2 steps (slope r0)", "lean_div(1, s)"};
+        for (int k = 0; k < 6; ++k) bad[k] = 0;
+        for (int k = 0; k < 24; ++k) first[k] = 0;
+        const uint32_t lo = 0x1F800000u, hi = 0x5F800000u;
+        const unsigned long long n = hi - lo;
+        hipLaunchKernelGGL(scan_rcp, dim3((n + 255) / 256), dim3(256), 0, 0, lo, n, bad, first);
+        hipDeviceSynchronize();
+        printf("1 / s, floats [2^-64, 2^64): %llu\n", n);
+        for (int k = 0; k < 5; ++k) printf("  %-26s mismatches vs 1.0f / s: %llu   first: %08x %08x\n", rnames[k], bad[k], first[4*k], first[4*k+1]);
     }
     return 0;
 }

@@ -92,7 +92,7 @@ SIGNATURES = {
     "rtGetLastKernel": (C.c_int, [_VP, C.POINTER(C.c_uint32)]),
     "rtSelfTestArith": (C.c_int, [_VP, C.c_uint32, _VP, _VP, _VP, _VP, C.c_uint32]),
     "rtSelfTestChSkySteps": (C.c_int, [_VP, C.c_float, C.c_float, _VP, C.c_uint32, C.POINTER(C.c_uint32)]),
-    "rtSelfTestSqrtScan": (C.c_int, [_VP, C.c_float, C.c_float, C.POINTER(C.c_uint64), _VP, C.c_uint32]),
+    "rtSelfTestUnaryScan": (C.c_int, [_VP, C.c_uint32, C.c_float, C.c_float, C.POINTER(C.c_uint64), _VP, C.c_uint32]),
     "rtUboFromImage": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(RtUbo5)]),
     "rtCameraFromUbo": (C.c_int, [C.POINTER(RtUbo5), C.POINTER(RtCamera)]),
     "rtMakeCamera": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
@@ -345,11 +345,12 @@ class Context:
                "rtSelfTestArith")
         return out
 
-    def selftest_sqrt_scan(self, lo: float, hi: float, cap: int = 16):
-        """rtSelfTestSqrtScan: (number of floats in [lo, hi] on which the kernels' square root differs from sqrtf, the first few of them)."""
+    def selftest_unary_scan(self, fn: int, lo: float, hi: float, cap: int = 16):
+        """rtSelfTestUnaryScan: (number of floats in [lo, hi] on which the kernels' square root (fn 0) / reciprocal (fn 1) differs from
+        sqrtf / 1.0f / x, the first few of them)."""
         bad = C.c_uint64(0)
         first = np.zeros(max(cap, 1), np.uint32)
-        _check(self._h, self._lib.rtSelfTestSqrtScan(self._h, lo, hi, C.byref(bad), first.ctypes.data, cap), "rtSelfTestSqrtScan")
+        _check(self._h, self._lib.rtSelfTestUnaryScan(self._h, fn, lo, hi, C.byref(bad), first.ctypes.data, cap), "rtSelfTestUnaryScan")
         return int(bad.value), first[: min(cap, int(bad.value))].view(np.float32)
 
     def selftest_ch_sky_steps(self, lo: float, hi: float, cap: int = 4096) -> np.ndarray:

@@ -727,7 +727,7 @@ int rtGetLastKernel(RtContext* ctx, uint32_t* kernel_out) {
 int rtSelfTestArith(RtContext* ctx, uint32_t op, const float* a, const float* b, const float* c,
                     float* out, uint32_t n) {
     if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rtSelfTestArith: ctx is null");
-    if (!a || !b || !c || !out || n == 0 || op > 17)
+    if (!a || !b || !c || !out || n == 0 || op > 18)
         return fail(ctx, RT_ERR_INVALID, "rtSelfTestArith: bad arguments");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     float* d = nullptr;
@@ -763,23 +763,23 @@ int rtSelfTestChSkySteps(RtContext* ctx, float lo, float hi, RtChSkyStep* out, u
     return RT_OK;
 }
 
-int rtSelfTestSqrtScan(RtContext* ctx, float lo, float hi, uint64_t* mismatches, uint32_t* first, uint32_t cap) {
-    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rtSelfTestSqrtScan: ctx is null");
-    if (!mismatches || (cap != 0 && !first) || !(lo <= hi) || !(lo >= 0.0f) || !std::isfinite(hi))
-        return fail(ctx, RT_ERR_INVALID, "rtSelfTestSqrtScan: bad arguments");
+int rtSelfTestUnaryScan(RtContext* ctx, uint32_t fn, float lo, float hi, uint64_t* mismatches, uint32_t* first, uint32_t cap) {
+    if (!ctx) return fail(nullptr, RT_ERR_INVALID, "rtSelfTestUnaryScan: ctx is null");
+    if (fn > 1u || !mismatches || (cap != 0 && !first) || !(lo <= hi) || !(lo >= 0.0f) || !std::isfinite(hi))
+        return fail(ctx, RT_ERR_INVALID, "rtSelfTestUnaryScan: bad arguments");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     void* d = nullptr;
     RT_HIP(ctx, hipMalloc(&d, 8 + size_t(cap) * 4));
     unsigned long long* d_bad = static_cast<unsigned long long*>(d);
     uint32_t* d_first = reinterpret_cast<uint32_t*>(d_bad + 1);
     hipError_t e = hipMemsetAsync(d, 0, 8 + size_t(cap) * 4, ctx->stream);
-    if (e == hipSuccess) e = rtiow::launch_sqrt_scan(lo, hi, d_bad, d_first, cap, ctx->stream);
+    if (e == hipSuccess) e = rtiow::launch_unary_scan(fn, lo, hi, d_bad, d_first, cap, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     unsigned long long bad = 0;
     if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost);
     if (e == hipSuccess && cap != 0) e = hipMemcpy(first, d_first, size_t(cap) * 4, hipMemcpyDeviceToHost);
     (void)hipFree(d);
-    if (e != hipSuccess) return fail_hip(ctx, e, "rtSelfTestSqrtScan");
+    if (e != hipSuccess) return fail_hip(ctx, e, "rtSelfTestUnaryScan");
     *mismatches = bad;
     return RT_OK;
 }

@@ -227,8 +227,9 @@ enum : uint32_t {
 
 hipError_t launch_ch(const ChArgs& a, hipStream_t stream);
 // rtSelfTestChSkySteps: every float in [lo, hi] where the sky colour of raytrace06.comp:45-47 changes (see ch_sky_steps_kernel)
-// rtSelfTestSqrtScan: floats of [lo, hi] (positive) on which the kernels' six-instruction square root differs from sqrtf
-hipError_t launch_sqrt_scan(float lo, float hi, unsigned long long* bad, uint32_t* first, uint32_t cap, hipStream_t stream);
+// rtSelfTestUnaryScan: floats of [lo, hi] (positive) on which the kernels' six-instruction square root differs from sqrtf (fn 0), their
+// three-instruction reciprocal from 1.0f / x (fn 1)
+hipError_t launch_unary_scan(uint32_t fn, float lo, float hi, unsigned long long* bad, uint32_t* first, uint32_t cap, hipStream_t stream);
 hipError_t launch_ch_sky_steps(float lo, float hi, RtChSkyStep* out, uint32_t cap, uint32_t* count, hipStream_t stream);
 // the primary pass's cone cull run on the host (rtConeSelfTestHost): see rtiow_kernels.hip
 int cone_selftest_host(const RtCamera& cam, uint32_t width, uint32_t height, uint32_t pix_lo, uint32_t pix_hi,

@@ -57,9 +57,9 @@ DI f3 unit3(f3 a) {
     return mk(a.x * k, a.y * k, a.z * k);
 }
 DI float psqrt(float x);
-DI float pdiv(float a, float b);
+DI float precip(float s);
 DI f3 unit3_scattered(f3 a) {  // the same for a direction the kernels made themselves (see psqrt)
-    const float k = pdiv(1.0f, psqrt(dot3(a, a)));
+    const float k = precip(psqrt(dot3(a, a)));
     return mk(a.x * k, a.y * k, a.z * k);
 }
 
@@ -170,7 +170,7 @@ DI float lean_div(float a, float b) {
 }
 // The correctly rounded square root in SIX instructions: v_rsq_f32 and one Newton step on the root, g = x y, h = y / 2, s = g + (x - g g) h.
 // That the step lands on RN(sqrt(x)) is not a theorem about one-ulp starting values -- it is a fact about this GPU's v_rsq_f32, and a
-// function of ONE float can be checked on every float: rtSelfTestSqrtScan evaluates it on all 1 879 048 192 floats of [2^-96, 2^128)
+// function of ONE float can be checked on every float: rtSelfTestUnaryScan (function 0) evaluates it on all 1 879 048 192 floats of [2^-96, 2^128)
 // against sqrtf -- no mismatch (tests/test_gpu_parity.py; tools/sqrt_scan.hip tried five such forms, all exact there, this is the
 // shortest).  The operand is kept away from zero by one v_max_f32, so that +0 gives +0 and -0 gives -0 (y = 2^63, g = +-0, s = +-0);
 // NaN gives NaN (g is NaN).  NOT for negative operands (a negative number comes out where sqrtf gives NaN) nor +inf (NaN): the one
@@ -180,6 +180,13 @@ DI float newton_sqrt(float x) {
     const float y = __builtin_amdgcn_rsqf(__builtin_fmaxf(x, 0x1p-126f));
     const float g = x * y, h = 0.5f * y;
     return fma_(fma_(-g, g, x), h, g);
+}
+// ... and the correctly rounded reciprocal in THREE: v_rcp_f32 and one Newton step.  The same kind of fact, checked the same way:
+// equal to 1.0f / s on every float of [2^-64, 2^64) (rtSelfTestUnaryScan, function 1; the compiler's core, lean_div(1, s), takes eight
+// instructions).  unit3_scattered's 1 / sqrt(dot): the root lies in [1e-8, 4).
+DI float newton_rcp(float s) {
+    const float r = __builtin_amdgcn_rcpf(s);
+    return fma_(fma_(-s, r, 1.0f), r, r);
 }
 
 // PATH mode takes the same lean forms wherever their precondition holds for EVERY input the kernels can see (psqrt, pdiv: 10 and 8
@@ -202,14 +209,15 @@ DI float newton_sqrt(float x) {
 //   * resolve_pixel: scale * sum with scale >= 2^-48 and sum an integer: 0 or >= 2^-48.
 // Late in round 4 the square roots became newton_sqrt (six instructions, above) at every site but the dielectric's 1 - cos^2, the only
 // operand that can be negative: for x == 0 or x >= 2^-96 it IS sqrtf(x), like lean_sqrt, so every argument above stands; the lock-step
-// test of the large spheres takes the root of any discriminant and reads it only when the discriminant is >= +0.
+// test of the large spheres takes the root of any discriminant and reads it only when the discriminant is >= +0.  The one quotient of
+// the kernels, unit3_scattered's 1 / length, became newton_rcp (three instructions).
 // -DRTIOW_LEAN_PATH=0: hipcc's forms everywhere; =1: lean_sqrt everywhere (A/B and parity checks of the above: the frames are the same).
 #ifndef RTIOW_LEAN_PATH
 #define RTIOW_LEAN_PATH 2
 #endif
 DI float psqrt(float x) { return RTIOW_LEAN_PATH == 2 ? newton_sqrt(x) : RTIOW_LEAN_PATH ? lean_sqrt(x) : __builtin_sqrtf(x); }
 DI float psqrt_signed(float x) { return RTIOW_LEAN_PATH ? lean_sqrt(x) : __builtin_sqrtf(x); }  // NaN for a negative operand, as sqrtf
-DI float pdiv(float a, float b) { return RTIOW_LEAN_PATH ? lean_div(a, b) : a / b; }
+DI float precip(float s) { return RTIOW_LEAN_PATH == 2 ? newton_rcp(s) : RTIOW_LEAN_PATH ? lean_div(1.0f, s) : 1.0f / s; }  // unit3_scattered's 1 / length
 
 #ifndef RTIOW_TU_PART
 // ch_kernel_tiles: the shaders as the reference dispatches them -- 16x16 workgroup as raytrace06.comp:2, one lane per
@@ -3378,6 +3386,7 @@ __global__ void arith_kernel(uint32_t op, const float* a, const float* b, const 
         case 14: r = __uint_as_float(ch_normal_two_phase(mk(a[i], b[i], c[i]))); break;                // the normal colour of v
         case 15: { const f3 v = mk(a[i], b[i], c[i]); r = __uint_as_float(ch_normal_colour<true>(v, lean_sqrt(gdot(v, v)))); break; }
         case 17: r = newton_sqrt(a[i]); break;  // the six-instruction square root of the PATH kernels and the two-phase CH pixels
+        case 18: r = newton_rcp(a[i]); break;   // the three-instruction reciprocal of unit3_scattered
         case 16: { bool second; const uint32_t col = ch_sky_phase1(reinterpret_cast<const uint4*>(ch_sky_table_words), a[i], second); r = __uint_as_float(second ? kChPhase2Flag : col); break; }  // the table alone
         default: break;
     }
@@ -3399,13 +3408,16 @@ __global__ __launch_bounds__(256) void ch_sky_steps_kernel(long long key_lo, uns
         if (at < cap) out[at] = RtChSkyStep{y, before, after};
     }
 }
-// newton_sqrt against sqrtf on every float of [lo, hi] (bit patterns of positive floats, ascending): the number of floats on which the
-// two differ, and the first few of them.  rtSelfTestSqrtScan; the proof of newton_sqrt is this kernel's zero over [2^-96, 2^128).
-__global__ __launch_bounds__(256) void sqrt_scan_kernel(uint32_t lo_bits, unsigned long long n, unsigned long long* bad, uint32_t* first, uint32_t cap) {
+// newton_sqrt against sqrtf (fn 0) or newton_rcp against 1.0f / x (fn 1) on every float of [lo, hi] (bit patterns of positive floats,
+// ascending): the number of floats on which the two differ, and the first few of them.  rtSelfTestUnaryScan; the proof of the two short
+// forms is this kernel's zero over [2^-96, 2^128) and [2^-64, 2^64).
+__global__ __launch_bounds__(256) void unary_scan_kernel(uint32_t fn, uint32_t lo_bits, unsigned long long n, unsigned long long* bad, uint32_t* first,
+                                                         uint32_t cap) {
     const unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * 256ull + threadIdx.x;
     if (i >= n) return;
     const float x = __uint_as_float(lo_bits + static_cast<uint32_t>(i));
-    if (__float_as_uint(newton_sqrt(x)) != __float_as_uint(__builtin_sqrtf(x))) {
+    const float got = fn == 0u ? newton_sqrt(x) : newton_rcp(x), want = fn == 0u ? __builtin_sqrtf(x) : 1.0f / x;
+    if (__float_as_uint(got) != __float_as_uint(want)) {
         const unsigned long long at = atomicAdd(bad, 1ull);
         if (at < cap) first[at] = __float_as_uint(x);
     }
@@ -3825,13 +3837,13 @@ hipError_t launch_ch_sky_steps(float lo, float hi, RtChSkyStep* out, uint32_t ca
     return hipGetLastError();
 }
 
-hipError_t launch_sqrt_scan(float lo, float hi, unsigned long long* bad, uint32_t* first, uint32_t cap, hipStream_t stream) {
+hipError_t launch_unary_scan(uint32_t fn, float lo, float hi, unsigned long long* bad, uint32_t* first, uint32_t cap, hipStream_t stream) {
     uint32_t b0, b1;
     std::memcpy(&b0, &lo, 4);
     std::memcpy(&b1, &hi, 4);
     if ((b0 | b1) & 0x80000000u || b1 < b0) return hipErrorInvalidValue;  // positive floats, ascending
     const unsigned long long n = static_cast<unsigned long long>(b1 - b0) + 1ull;
-    hipLaunchKernelGGL(sqrt_scan_kernel, dim3(static_cast<uint32_t>((n + 255ull) / 256ull)), dim3(256), 0, stream, b0, n, bad, first, cap);
+    hipLaunchKernelGGL(unary_scan_kernel, dim3(static_cast<uint32_t>((n + 255ull) / 256ull)), dim3(256), 0, stream, fn, b0, n, bad, first, cap);
     return hipGetLastError();
 }
 
