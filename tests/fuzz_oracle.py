@@ -27,5 +27,7 @@ with V.Context(0) as ctx:
                 bad += 1
                 print(f"MISMATCH case {case} kernel {kern} n={len(sph)} {w}x{h}", flush=True)
         done += 1
+        if done % 200 == 0:  # (a run that writes nothing for minutes is taken to be hung)
+            print(f"... {done} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
 print(f"{done} cases x 4 kernels (4 = the clustered list with the primary pass forced on) against the oracle, {bad} mismatches, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
