@@ -185,7 +185,10 @@ int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materi
  *      happens before anything of the frame is enqueued: the host waits for THIS context's previous frame (other contexts'
  *      frames on the device are not touched), builds (RtSceneStats.last_cluster_build_ms; not part of the frame's kernel_ms)
  *      and re-uploads.  Beyond 64 diagonals the frame is rendered with the flat list.  Rare (a fly-away camera), never wrong.
- *      max_depth above 524287 is refused (the kernels count a path's segments in 19 bits). */
+ *      max_depth above 524287 is refused (the kernels count a path's segments in 19 bits), and so is a camera whose rays --
+ *      from the lens to any point of its image plane -- could be shorter than 2^-30 or longer than 2^40, or whose image plane
+ *      is degenerate (horizontal x vertical = 0): the kernels normalise a ray by a square root and a reciprocal that are
+ *      exact inside that range (rtSelfTestUnaryScan). */
 int rtRender(RtContext* ctx, const RtCamera* cam, const RtParams* params, void* dst,
              size_t dst_pitch, int dst_is_device, void* stream);
 

@@ -654,8 +654,8 @@ def test_a_camera_that_moves_every_frame(oracle):
 def test_round4_boundary_additions(gpu_ctx, rt):
     """ABI 4: the frame's kernel reports the shader clock it ran at (RtStats.shader_clock_mhz: a plausible MI355X clock after a PATH
     frame, 0 after one of the reference's shaders), rtGetSceneStats says what rtSetScene made of the scene, and the two limits the
-    round-4 kernels rely on are refused at the door: max_depth beyond the 19 bits a path's depth is counted in, and a tile of 2^29
-    pixels or more."""
+    round-4 kernels rely on are refused at the door: max_depth beyond the 19 bits a path's depth is counted in, a tile of 2^29
+    pixels or more, and a camera whose rays could be shorter than 2^-30 or longer than 2^40."""
     sph, mat = V.make_cover_scene(1, 11)
     gpu_ctx.set_scene(sph, mat)
     ss = gpu_ctx.scene_stats()
@@ -672,4 +672,16 @@ def test_round4_boundary_additions(gpu_ctx, rt):
     gpu_ctx.render(cam, V.make_params(64, 48, spp=1, max_depth=(1 << 19) - 1, seed=1))  # (the largest depth accepted)
     with pytest.raises(rt.RtError) as e:  # 32768 x 16384 = 2^29 pixels: refused before anything is allocated
         gpu_ctx.render_device(cam, V.make_params(32768, 16384, spp=1, max_depth=1, seed=1), 4096, 32768 * 4)
+    assert e.value.code == V.RT_ERR_INVALID
+    # a camera whose rays could leave [2^-30, 2^40] (the domain of the kernels' short root and reciprocal) or whose image plane is degenerate
+    for bad in (V.make_camera((13e-12, 2e-12, 3e-12), (0, 0, 0), (0, 1, 0), 20.0, 1.5, 0.0, 1e-11),   # a scene of picometres
+                V.make_camera((13e13, 2e13, 3e13), (0, 0, 0), (0, 1, 0), 20.0, 1.5, 0.0, 1e14)):       # ... of light-days
+        with pytest.raises(rt.RtError) as e:
+            gpu_ctx.render(bad, V.make_params(64, 48, spp=1, max_depth=1, seed=1))
+        assert e.value.code == V.RT_ERR_INVALID
+    flat = V.make_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, 1.5, 0.1, 10.0)
+    for k in range(3):
+        flat.vertical[k] = flat.horizontal[k]
+    with pytest.raises(rt.RtError) as e:
+        gpu_ctx.render(flat, V.make_params(64, 48, spp=1, max_depth=1, seed=1))
     assert e.value.code == V.RT_ERR_INVALID

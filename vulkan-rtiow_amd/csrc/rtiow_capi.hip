@@ -501,6 +501,8 @@ int rtRender(RtContext* ctx, const RtCamera* cam, const RtParams* params, void* 
         return fail(ctx, RT_ERR_INVALID, "rtRender: max_depth must be at least 1");
     if (params->max_depth > rtiow::kMaxPathDepth)
         return fail(ctx, RT_ERR_INVALID, "rtRender: max_depth must not exceed 524287");
+    if (!rtiow::camera_rays_moderate(*cam))
+        return fail(ctx, RT_ERR_INVALID, "rtRender: camera rays must be between 2^-30 and 2^40 long (and the image plane not degenerate)");
     if (params->accumulate && (params->sample_offset > 65536u - params->spp))
         return fail(ctx, RT_ERR_INVALID, "rtRender: sample_offset + spp must not exceed 65536");
     if (params->quantiser > RT_QUANT_BOOK) return fail(ctx, RT_ERR_INVALID, "rtRender: unknown quantiser");

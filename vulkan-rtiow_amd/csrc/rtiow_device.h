@@ -3,7 +3,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cmath>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/rtiow.h"
@@ -224,6 +226,43 @@ enum : uint32_t {
                                // samples per pixel; 0 and 3 use it from 8 samples per pixel on (large scenes: always).
                                // Reported as 3.
 };
+
+// Is every camera ray's length within [2^-30, 2^40]?  rtRender's precondition since late round 4: the kernels normalise a camera ray
+// by the short square root and reciprocal (newton_sqrt, newton_rcp: exact on [2^-96, 2^128) and [2^-64, 2^64), rtiow_kernels.hip), as
+// they do the rays they scatter themselves.  A ray runs from the lens to a point A + u H + v V of the image plane (A = lower_left -
+// origin): no shorter than the plane's distance from the origin less the lens offset's component along the plane's normal, no longer than the farthest corner (u, v <= 2: u = (i +
+// xi) / (W - 1)) plus the lens; the float evaluation is off by a few ulps of the LONGEST term, so the shortest ray must also be above
+// 2^-18 of the longest.  In double; false for a degenerate (H x V = 0) or non-finite camera.
+inline bool camera_rays_moderate(const RtCamera& c) {
+    double A[3], H[3], V[3], n[3];
+    for (int k = 0; k < 3; ++k) {
+        A[k] = double(c.lower_left[k]) - c.origin[k];
+        H[k] = c.horizontal[k];
+        V[k] = c.vertical[k];
+    }
+    n[0] = H[1] * V[2] - H[2] * V[1];
+    n[1] = H[2] * V[0] - H[0] * V[2];
+    n[2] = H[0] * V[1] - H[1] * V[0];
+    auto norm = [](const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+    const double nn = norm(n);
+    if (!(nn > 0.0) || !std::isfinite(nn)) return false;
+    const double uvec[3] = {c.u[0], c.u[1], c.u[2]}, vvec[3] = {c.v[0], c.v[1], c.v[2]};
+    auto along_n = [&](const double* v) { return std::fabs(v[0] * n[0] + v[1] * n[1] + v[2] * n[2]) / nn; };
+    const double lens = c.lens_radius > 0.0f ? double(c.lens_radius) * (norm(uvec) + norm(vvec)) : 0.0;
+    // (the lens offset x u + y v, |x|, |y| <= lens_radius, shortens a ray only by its component along the plane's normal: none for the
+    // usual camera, whose u and v lie in the plane -- a lens wider than the focus distance is fine)
+    const double lens_n = c.lens_radius > 0.0f ? double(c.lens_radius) * (along_n(uvec) + along_n(vvec)) : 0.0;
+    const double nearest = along_n(A) - lens_n;
+    double farthest = 0.0, term = norm(A) + 2.0 * norm(H) + 2.0 * norm(V) + lens;
+    for (int k = 0; k < 3; ++k) term = std::max(term, std::fabs(double(c.origin[k])) + std::fabs(double(c.lower_left[k])));
+    for (int cu = 0; cu < 2; ++cu)
+        for (int cv = 0; cv < 2; ++cv) {
+            double P[3];
+            for (int k = 0; k < 3; ++k) P[k] = A[k] + 2.0 * cu * H[k] + 2.0 * cv * V[k];
+            farthest = std::max(farthest, norm(P) + lens);
+        }
+    return std::isfinite(term) && nearest >= 0x1p-30 && farthest <= 0x1p40 && term <= 0x1p40 && nearest >= term * 0x1p-18;
+}
 
 hipError_t launch_ch(const ChArgs& a, hipStream_t stream);
 // rtSelfTestChSkySteps: every float in [lo, hi] where the sky colour of raytrace06.comp:45-47 changes (see ch_sky_steps_kernel)

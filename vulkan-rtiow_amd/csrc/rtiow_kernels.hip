@@ -204,8 +204,8 @@ DI float newton_rcp(float s) {
 //     apart at most; a metal or glass direction is a reflection or refraction of a unit vector (length 1 to a few ulps), a fuzzed one the
 //     sum of a unit vector and fuzz <= 1 times another, which comes out exactly 0 (absorbed before unit3: dir . n > 0 fails) or with a
 //     component of at least 2^-25 unless all three cancel to within 2^-48 of their operands at once -- 2^-72 of the fuzzed samples
-//     would have to; such a sample may differ from the oracle in its last bits.  unit3 of a CAMERA ray keeps hipcc's forms: its length is
-//     whatever the caller's camera makes it;
+//     would have to; such a sample may differ from the oracle in its last bits.  unit3 of a CAMERA ray kept hipcc's forms until late in
+//     round 4 (its length is whatever the caller's camera makes it); rtRender now bounds that length (camera_rays_moderate);
 //   * resolve_pixel: scale * sum with scale >= 2^-48 and sum an integer: 0 or >= 2^-48.
 // Late in round 4 the square roots became newton_sqrt (six instructions, above) at every site but the dielectric's 1 - cos^2, the only
 // operand that can be negative: for x == 0 or x >= 2^-96 it IS sqrtf(x), like lean_sqrt, so every argument above stands; the lock-step
@@ -690,7 +690,9 @@ DI void camera_path(const PathArgs& a, uint32_t i, uint32_t j, uint32_t sample, 
     d.x = fma_(v, c.vertical[0], fma_(u, c.horizontal[0], c.lower_left[0])) - c.origin[0] - off.x;
     d.y = fma_(v, c.vertical[1], fma_(u, c.horizontal[1], c.lower_left[1])) - c.origin[1] - off.y;
     d.z = fma_(v, c.vertical[2], fma_(u, c.horizontal[2], c.lower_left[2])) - c.origin[2] - off.z;
-    p.du = unit3(d);
+    // (rtRender refuses a camera whose rays could be shorter than 2^-30 or longer than 2^40 -- camera_rays_moderate, rtiow_device.h --
+    // so the ray's length is inside the short root's and reciprocal's domains like that of a scattered ray)
+    p.du = RTIOW_LEAN_PATH == 2 ? unit3_scattered(d) : unit3(d);
     p.att = mk(1.0f, 1.0f, 1.0f);
 }
 
