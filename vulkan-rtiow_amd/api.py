@@ -360,7 +360,7 @@ class Context:
         n = C.c_uint32(0)
         _check(self._h, self._lib.rtSelfTestChSkySteps(self._h, lo, hi, out.ctypes.data, cap, C.byref(n)), "rtSelfTestChSkySteps")
         if n.value > cap:
-            raise RtiowError(RT_ERR_INVALID, f"{n.value} steps, room for {cap}")
+            raise RtError(RT_ERR_INVALID, "rtSelfTestChSkySteps", f"{n.value} steps, room for {cap}")
         return np.sort(out[: n.value], order="unit_y")
 
 
