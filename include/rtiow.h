@@ -192,6 +192,10 @@ int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materi
 int rtRender(RtContext* ctx, const RtCamera* cam, const RtParams* params, void* dst,
              size_t dst_pitch, int dst_is_device, void* stream);
 
+/* rtRender's precondition on the camera, for a caller to ask beforehand: 1 if every ray from the lens to a point of the image
+ * plane is between 2^-30 and 2^40 long and the image plane is not degenerate, else 0 (also for NULL).  No context, no GPU. */
+int rtCameraIsRenderable(const RtCamera* cam);
+
 /* The reference's own call shape: 20-byte UBO in, image out
  * (RTCHAP06/main.cpp:109-124 + :313-325).  mode is RT_MODE_CH05/CH06.
  * The image is the shaders' byte for byte (raytrace05.comp / raytrace06.comp evaluated in IEEE float32 without contraction,

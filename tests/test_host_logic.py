@@ -492,3 +492,25 @@ def test_ch_sky_steps_follow_the_quantiser():
     assert max(abs(a - b) for a, b in zip(merged, centres)) < 2e-6
     assert all((s[1] ^ s[2]) & 0xFF0000 == 0 for s in steps)  # blue never changes
     assert steps[0][1] == 0xFFFFFF and int(gen.F(np.float32(1.0))) & 0xFF00FF == 0xFF0080  # white at the nadir, (0.5, 0.7, 1) at the zenith
+
+
+def test_camera_precondition_accepts_every_sane_camera_and_refuses_the_rest():
+    """rtRender refuses a camera whose rays -- lens to image plane -- could be shorter than 2^-30 or longer than 2^40 (the kernels' short
+    square root and reciprocal are exact inside that range; rtCameraIsRenderable is the check, no GPU needed).  Every camera the tests,
+    the bench and the harness use passes -- lenses wider than the focus distance, a 179-degree fish-eye, a camera kilometres out -- and
+    scenes of picometres or light-days, a non-finite camera and a degenerate image plane do not."""
+    ok = [((13, 2, 3), (0, 0, 0), 20.0, 0.1, 10.0), ((13, 2, 3), (0, 0, 0), 20.0, 6.0, 1.0), ((3, 0.6, 2), (0, 0.5, 0), 179.0, 0.0, 1.0),
+          ((40, 6, 9), (0, 0, 0), 8.0, 0.0, 40.0), ((0.3, 0.25, 0.4), (4, 0.2, 3), 90.0, 0.05, 2.0), ((4e4, 2e3, 3e4), (0, 0, 0), 1.0, 0.0, 5e4),
+          ((1e-3, 2e-3, 3e-3), (0, 0, 0), 40.0, 1e-5, 3.7e-3), ((13, 2, 3), (0, 0, 0), 0.01, 0.0, 10.0)]
+    for frm, at, fov, ap, focus in ok:
+        for aspect in (0.25, 1.5, 8.0):
+            assert V.camera_is_renderable(V.make_camera(frm, at, (0, 1, 0), fov, aspect, ap, focus)), (frm, fov, ap, focus, aspect)
+    bad = [V.make_camera((13e-12, 2e-12, 3e-12), (0, 0, 0), (0, 1, 0), 20.0, 1.5, 0.0, 1e-11),
+           V.make_camera((13e13, 2e13, 3e13), (0, 0, 0), (0, 1, 0), 20.0, 1.5, 0.0, 1e14)]
+    flat = V.make_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, 1.5, 0.1, 10.0)
+    for k in range(3):
+        flat.vertical[k] = flat.horizontal[k]
+    nan = V.make_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, 1.5, 0.1, 10.0)
+    nan.lower_left[1] = float("nan")
+    for cam in bad + [flat, nan]:
+        assert not V.camera_is_renderable(cam)

@@ -9,5 +9,5 @@ module `vulkan_rtiow_amd` at the repo root (or importlib.import_module).
 from . import api  # noqa: F401
 from .api import *  # noqa: F401,F403
 from .api import (Context, MultiContext, RtError, chunk_order_selftest_host, cluster_build_host, cone_selftest_host, load_library,  # noqa: F401
-                  scene_cluster_selftest_host,
+                  scene_cluster_selftest_host, camera_is_renderable,
                   multi_selftest_host)  # noqa: F401

@@ -116,6 +116,7 @@ SIGNATURES = {
     "rtChunkOrderSelfTestHost": (C.c_int, [C.c_uint32, _VP, _VP]),
     "rtClusterBuildHost": (C.c_int, [_VP, C.c_uint32, C.c_float, _VP, _VP, C.c_uint32, _VP, _VP, _VP, C.c_uint32, _VP, _VP, _VP, _VP]),
     "rtSceneClusterSelfTestHost": (C.c_int, [_VP, C.c_uint32, _VP, _VP, _VP]),
+    "rtCameraIsRenderable": (C.c_int, [_VP]),
     "rtGetSceneStats": (C.c_int, [_VP, _VP]),
     "rtConeSelfTestHost": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _VP, C.c_float, _VP, C.c_uint32,
                                      _VP, C.c_uint32, _VP, _VP]),
@@ -462,6 +463,11 @@ def cluster_build_host(spheres: np.ndarray, range_diags: float = 2.0) -> dict:
     return {"n_clusters": nc.value, "n_super": ns.value, "boxes": boxes[:n].copy(), "flat_boxes": flat[:n].copy(),
             "slot_index": slots[:nslots.value].copy(), "n_large_slots": nlarge.value, "flat_axis": axis.value,
             "flat_interval": (float(interval[0]), float(interval[1]))}
+
+
+def camera_is_renderable(cam: "RtCamera") -> bool:
+    """rtCameraIsRenderable: rtRender's precondition on the camera (ray lengths within [2^-30, 2^40], image plane not degenerate)."""
+    return bool(load_library().rtCameraIsRenderable(C.byref(cam)))
 
 
 def scene_cluster_selftest_host(spheres: np.ndarray) -> dict:

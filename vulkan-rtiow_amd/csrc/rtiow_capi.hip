@@ -669,6 +669,10 @@ int rtClusterBuildHost(const RtSphere* spheres, uint32_t n_spheres, float range_
     return RT_OK;
 }
 
+int rtCameraIsRenderable(const RtCamera* cam) {  // rtRender's precondition on the camera, for a caller to ask beforehand (no GPU needed)
+    return cam != nullptr && rtiow::camera_rays_moderate(*cam) ? 1 : 0;
+}
+
 int rtSceneClusterSelfTestHost(const RtSphere* spheres, uint32_t n_spheres, uint32_t* builds_out, double* range_out,
                                uint32_t* n_super_out) {
     if (!spheres || n_spheres == 0 || !builds_out || !range_out || !n_super_out)
