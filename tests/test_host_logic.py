@@ -501,7 +501,8 @@ def test_camera_precondition_accepts_every_sane_camera_and_refuses_the_rest():
     scenes of picometres or light-days, a non-finite camera and a degenerate image plane do not."""
     ok = [((13, 2, 3), (0, 0, 0), 20.0, 0.1, 10.0), ((13, 2, 3), (0, 0, 0), 20.0, 6.0, 1.0), ((3, 0.6, 2), (0, 0.5, 0), 179.0, 0.0, 1.0),
           ((40, 6, 9), (0, 0, 0), 8.0, 0.0, 40.0), ((0.3, 0.25, 0.4), (4, 0.2, 3), 90.0, 0.05, 2.0), ((4e4, 2e3, 3e4), (0, 0, 0), 1.0, 0.0, 5e4),
-          ((1e-3, 2e-3, 3e-3), (0, 0, 0), 40.0, 1e-5, 3.7e-3), ((13, 2, 3), (0, 0, 0), 0.01, 0.0, 10.0)]
+          ((1e-3, 2e-3, 3e-3), (0, 0, 0), 40.0, 1e-5, 3.7e-3), ((13, 2, 3), (0, 0, 0), 0.01, 0.0, 10.0),
+          ((1e6, 2.0, 3.0), (1e6 + 4, 0, 0), 30.0, 0.0, 4.0)]  # a million units out, focused four units ahead
     for frm, at, fov, ap, focus in ok:
         for aspect in (0.25, 1.5, 8.0):
             assert V.camera_is_renderable(V.make_camera(frm, at, (0, 1, 0), fov, aspect, ap, focus)), (frm, fov, ap, focus, aspect)
@@ -512,5 +513,6 @@ def test_camera_precondition_accepts_every_sane_camera_and_refuses_the_rest():
         flat.vertical[k] = flat.horizontal[k]
     nan = V.make_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, 1.5, 0.1, 10.0)
     nan.lower_left[1] = float("nan")
+    bad.append(V.make_camera((1e6, 2.0, 3.0), (1e6 + 0.5, 0, 0), (0, 1, 0), 30.0, 1.5, 0.0, 0.5))  # ... half a unit: the float ray is noise
     for cam in bad + [flat, nan]:
         assert not V.camera_is_renderable(cam)

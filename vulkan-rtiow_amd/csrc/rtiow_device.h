@@ -231,8 +231,8 @@ enum : uint32_t {
 // by the short square root and reciprocal (newton_sqrt, newton_rcp: exact on [2^-96, 2^128) and [2^-64, 2^64), rtiow_kernels.hip), as
 // they do the rays they scatter themselves.  A ray runs from the lens to a point A + u H + v V of the image plane (A = lower_left -
 // origin): no shorter than the plane's distance from the origin less the lens offset's component along the plane's normal, no longer than the farthest corner (u, v <= 2: u = (i +
-// xi) / (W - 1)) plus the lens; the float evaluation is off by a few ulps of the LONGEST term, so the shortest ray must also be above
-// 2^-18 of the longest.  In double; false for a degenerate (H x V = 0) or non-finite camera.
+// xi) / (W - 1)) plus the lens; the float evaluation is off by a few ulps of the LONGEST term, which comes off the shortest ray.
+// In double; false for a degenerate (H x V = 0) or non-finite camera.
 inline bool camera_rays_moderate(const RtCamera& c) {
     double A[3], H[3], V[3], n[3];
     for (int k = 0; k < 3; ++k) {
@@ -261,7 +261,9 @@ inline bool camera_rays_moderate(const RtCamera& c) {
             for (int k = 0; k < 3; ++k) P[k] = A[k] + 2.0 * cu * H[k] + 2.0 * cv * V[k];
             farthest = std::max(farthest, norm(P) + lens);
         }
-    return std::isfinite(term) && nearest >= 0x1p-30 && farthest <= 0x1p40 && term <= 0x1p40 && nearest >= term * 0x1p-18;
+    // (each component of the ray is four rounded operations on terms no larger than `term`, u and v two more: off by less than 2^-21
+    // term in length.  A camera a million units from the origin can still focus four units ahead.)
+    return std::isfinite(term) && farthest <= 0x1p40 && term <= 0x1p40 && nearest - term * 0x1p-20 >= 0x1p-30;
 }
 
 hipError_t launch_ch(const ChArgs& a, hipStream_t stream);
