@@ -21,6 +21,16 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.rtAbiVersion() == 4
+    # ... and NOTHING else (crc32_update, put_be32, write_chunk and the rtiow:: / std:: internals used to be visible to, and
+    # interposable by, the application the library is linked into): csrc/rtiow.map
+    import subprocess
+    for so in ("librtiow_hip.so", "librtiow_hip_knobs.so"):
+        path = os.path.join(ROOT, "vulkan-rtiow_amd", so)
+        if not os.path.exists(path):
+            continue
+        out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+        exported = {line.split()[-1].split("@")[0] for line in out.splitlines() if line.strip()}
+        assert exported == declared, (so, sorted(exported ^ declared))
 
 
 def test_chunk_order_fits_its_allocation():

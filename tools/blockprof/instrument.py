@@ -1,0 +1,87 @@
+"""Basic-block execution counters for one gfx950 kernel, put into its ASSEMBLY (tools/blockprof/build.sh drives this).
+
+rocprofv3's PC sampling and thread trace are not available on this GPU pool, and the SQ counters class instructions only coarsely
+(fma / mul / add / cvt / trans / int: 61 % of the path kernel's vector instructions; the rest -- moves, selects, compares, v_readlane /
+v_writelane of spilled scalars, DPP -- is one lump).  This tool counts EXACTLY instead: in front of every basic block of the kernel it
+inserts one scalar memory atomic (s_atomic_add, which gfx950 executes: tools/blockprof/satomic_test.hip) on the block's own counter, so
+that after a frame `count[b]` is the number of times a wave entered block b; tools/blockprof/report.py multiplies that by the block's
+static instruction list.  The sums must reproduce the SQ_INSTS_* counters of the un-instrumented kernel, which is the tool's own check.
+
+Inserted per block (wave-uniform, EXEC-independent, SCC / VCC / EXEC / M0 untouched):
+    v_writelane_b32 vS, s0..s2 -> lanes 0..2      save three scalars in a spare vector register
+    v_readlane_b32  s0, s1 <- vB lanes 0, 1       the counter array's address (put there by the kernel's first instructions)
+    s_mov_b32 s2, 1 ; s_atomic_add s2, s[0:1], 128 * b ; s_waitcnt lgkmcnt(0)
+    v_readlane_b32  s0..s2 <- vS ; s_nop 4        restore (the nops: a VALU-written SGPR must age before VMEM / lane-select reads it)
+vS, vB are the two vector registers after the kernel's own (.amdhsa_next_free_vgpr is raised by two).
+
+usage: instrument.py in.s out.s map.json <kernel-name-substring> <kernarg offset of PathArgs::counters> <offset of Counters::block_counts>
+"""
+import json, re, sys
+
+src, dst, map_path, key, off_counters, off_blocks = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5], 0), int(sys.argv[6], 0)
+STRIDE = 128  # bytes between counters: one 128-byte line each, so that hot blocks do not queue behind each other in one L2 channel
+lines = open(src).read().split("\n")
+start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l) and key in l)
+name = lines[start].split(":")[0]
+# the kernel's descriptor (it follows the code, in front of .Lfunc_end): registers in use
+desc = next(i for i in range(start, len(lines)) if ".amdhsa_kernel " + name in lines[i])
+end = next(i for i in range(start, desc) if lines[i].lstrip().startswith(".section"))  # (the code ends where .rodata begins)
+nfv_i = next(i for i in range(desc, len(lines)) if ".amdhsa_next_free_vgpr" in lines[i])
+nfv = int(lines[nfv_i].split()[-1])
+acc_i = next(i for i in range(desc, len(lines)) if ".amdhsa_accum_offset" in lines[i])
+vS, vB = nfv, nfv + 1
+lines[nfv_i] = f"\t\t.amdhsa_next_free_vgpr {nfv + 2}"
+lines[acc_i] = f"\t\t.amdhsa_accum_offset {(nfv + 2 + 3) // 4 * 4}"
+
+INSTR = re.compile(r"^\s+([a-z][a-z0-9_]+)\b(.*)$")
+BRANCH = re.compile(r"^(s_cbranch_\w+|s_branch|s_setpc_b64|s_swappc_b64|s_endpgm)$")
+LABEL = re.compile(r"^(\.LBB\d+_\d+|_Z\w+):")
+
+
+def counter_code(b):
+    return [f"\t; ---- blockprof: block {b}",
+            f"\tv_writelane_b32 v{vS}, s0, 0", f"\tv_writelane_b32 v{vS}, s1, 1", f"\tv_writelane_b32 v{vS}, s2, 2",
+            f"\tv_readlane_b32 s0, v{vB}, 0", f"\tv_readlane_b32 s1, v{vB}, 1", "\ts_mov_b32 s2, 1", "\ts_nop 4",
+            f"\ts_atomic_add s2, s[0:1], 0x{b * STRIDE:x}", "\ts_waitcnt lgkmcnt(0)",
+            f"\tv_readlane_b32 s0, v{vS}, 0", f"\tv_readlane_b32 s1, v{vS}, 1", f"\tv_readlane_b32 s2, v{vS}, 2", "\ts_nop 4"]
+
+
+out = lines[:start + 1]
+blocks = []          # per block: list of [mnemonic, operands, source line]
+cur_line = 0         # last .loc line seen
+at_head = True       # the next instruction opens a block
+prologue_done = False
+for l in lines[start + 1:end]:
+    m = re.match(r"\s+\.loc\s+(\d+)\s+(\d+)", l)
+    if m:
+        cur_line = int(m.group(2)) if int(m.group(1)) <= 1 else -(int(m.group(1)) * 100000 + int(m.group(2)))  # (< 0: a line of another file)
+    if LABEL.match(l):
+        at_head = True
+        out.append(l)
+        continue
+    m = INSTR.match(l)
+    if not m or l.lstrip().startswith((".", ";")):
+        out.append(l)
+        continue
+    op, rest = m.group(1), m.group(2).split(";")[0].strip()
+    if at_head:
+        if not prologue_done:
+            # s[0:1] = kernarg segment; s[90:91] are not initialised at wave start
+            out += ["\t; ---- blockprof: address of Counters::block_counts into lanes 0, 1 of the spare register",
+                    f"\ts_load_dwordx2 s[90:91], s[0:1], 0x{off_counters:x}", "\ts_waitcnt lgkmcnt(0)",
+                    f"\ts_add_u32 s90, s90, 0x{off_blocks:x}", "\ts_addc_u32 s91, s91, 0",
+                    f"\tv_writelane_b32 v{vB}, s90, 0", f"\tv_writelane_b32 v{vB}, s91, 1", "\ts_nop 4"]
+            prologue_done = True
+        out += counter_code(len(blocks))
+        blocks.append([])
+        at_head = False
+    blocks[-1].append([op, rest, cur_line])
+    out.append(l)
+    if BRANCH.match(op):
+        at_head = True
+out += lines[end:]
+open(dst, "w").write("\n".join(out))
+files = {int(mm.group(1)): mm.group(2) for mm in (re.match(r'\s+\.file\s+(\d+)\s+"[^"]*"\s+"([^"]*)"', l) for l in lines) if mm}
+json.dump({"files": files, "kernel": name, "stride_bytes": STRIDE, "blocks": blocks, "spare_vgprs": [vS, vB]}, open(map_path, "w"))
+n_ins = sum(len(b) for b in blocks)
+print(f"{name}: {len(blocks)} blocks, {n_ins} instructions, {len(blocks) * 13 + 8} inserted; spare registers v{vS}, v{vB}; counters need {len(blocks) * STRIDE} bytes")

@@ -22,6 +22,11 @@ rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_WAVES GR
 #   4. lane occupancy of the vector instructions: SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU), and the rest of the mix
 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_INSTS_LDS_ATOMIC \
     --output-format csv -d $O/prof_${TAG}_lane -- $BENCH > $O/prof_${TAG}_lane.log 2>&1 || true
+#   4b. the executed instruction mix by class (round 5: tools/instruction_mix.py reads it): the vector classes the SQ counts apart, then the rest
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 \
+    --output-format csv -d $O/prof_${TAG}_mixa -- $BENCH > $O/prof_${TAG}_mixa.log 2>&1 || true
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_INSTS_LDS_ATOMIC SQ_INSTS_VMEM \
+    --output-format csv -d $O/prof_${TAG}_mixb -- $BENCH > $O/prof_${TAG}_mixb.log 2>&1 || true
 cd $R && python3 tools/profile_summary.py $TAG
 #   5. the reference's own kernels at sizes where bytes matter: kernel stats + PMC passes of tools/ch_bandwidth.py
 #      (third argument "noch": not for this tag -- e.g. the C5 leg: profile.sh r04_c5 "--workload cover4096_3840x2160_64spp" noch)

@@ -28,7 +28,7 @@ if os.path.exists(log):
             open(os.path.join(prof, f"{tag}_bench_under_rocprof.json"), "w").write(line)
 
 pmc = {}
-for kind in ("fetch", "write", "sq", "lds", "lane"):
+for kind in ("fetch", "write", "sq", "lds", "lane", "mixa", "mixb"):
     f = one(f"prof_{tag}_{kind}/**/*_counter_collection.csv")
     if not f:
         continue

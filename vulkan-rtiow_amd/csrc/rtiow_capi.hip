@@ -549,6 +549,14 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
         } else {  // (fetched here, not after every frame: one small copy less between two frames of a loop)
             RT_HIP(ctx, hipMemcpy(ctx->h_counters, ctx->d_counters + ctx->stats_index, sizeof(rtiow::Counters), hipMemcpyDeviceToHost));
         }
+#ifdef RTIOW_BLOCK_COUNTERS
+        if (const char* path = std::getenv("RTIOW_BLOCK_DUMP")) {  // (tools/blockprof builds only) one line per basic-block counter
+            if (FILE* f = fopen(path, "w")) {
+                for (uint32_t b = 0; b < RTIOW_BLOCK_COUNTERS; ++b) fprintf(f, "%u\n", ctx->h_counters->block_counts[b * 32u]);
+                fclose(f);
+            }
+        }
+#endif
         ctx->stats.paths = ctx->h_counters->paths;
         ctx->stats.segments = ctx->h_counters->segments;
         // persistent kernels count the tests they perform; the one-lane-per-pixel kernel tests every

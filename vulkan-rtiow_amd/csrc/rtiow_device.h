@@ -69,6 +69,12 @@ struct Counters {
     unsigned int tl_wave[8192][8];
     unsigned long long tl_bucket[5][4];  // sparse iterations by paths held (1-2, 3-4, 5-8, 9-16, 17-32): count, ticks, trace cycles, shade cycles
 #endif
+#ifdef RTIOW_BLOCK_COUNTERS
+    // tools/blockprof builds only: one execution counter per basic block of the instrumented kernel, each on a 128-byte line of its own
+    // (written by s_atomic_add instructions that tools/blockprof/instrument.py puts into the kernel's assembly; RTIOW_BLOCK_DUMP=file
+    // makes rtGetStats write them out)
+    alignas(128) unsigned int block_counts[RTIOW_BLOCK_COUNTERS * 32];
+#endif
 };
 
 // Device-side shading record of one sphere (32 B), built by rtSetScene from RtSphere + RtMaterial.
