@@ -249,3 +249,81 @@ def test_path_defocused_mirror_ball_known_answer(oracle):
     img, _ = oracle.render(sph, mat, defocus.camera(w, h), V.make_params(w, h, spp=2048, max_depth=50, seed=5))
     assert defocus.check(img, w, h, tol=3) <= 3
 
+
+
+# ---- the reference's compiled shaders as a second witness (tests/golden/make_spirv_witness.py) ----
+_SPV = json.load(open(os.path.join(GOLD, "spirv_witness.json")))
+
+
+@pytest.mark.parametrize("mode", ["CH05", "CH06"])
+@pytest.mark.parametrize("size", ["800x608", "400x225"])
+def test_oracle_frames_equal_the_reference_spirv_evaluated_in_binary32(oracle, mode, size):
+    """raytrace05.comp.spv / raytrace06.comp.spv -- the binaries RTCHAP05/RTCHAP05/main.cpp:136 and RTCHAP06/main.cpp:154 load --
+    were executed symbolically and the value `main` stores evaluated operation by operation in binary32 over whole frames
+    (generator: tests/golden/make_spirv_witness.py; conventions for what SPIR-V leaves to the driver in the file).  The oracle, which
+    restates the GLSL text, must give the same bytes: the one branch without a screenshot -- CH06's normals -- included."""
+    fr = _SPV["shaders"][mode]["frames"][size]
+    w, h = (int(x) for x in size.split("x"))
+    ubo = oracle.ubo_from_image(w, h)
+    assert [ubo.imageWidth, ubo.imageHeight, ubo.viewportWidth, ubo.viewportHeight, ubo.focalLength] == fr["ubo"]
+    img = oracle.render_ubo(ubo, V.RT_MODE_CH05 if mode == "CH05" else V.RT_MODE_CH06)
+    assert img[..., 3].max() == fr["alpha_max"] == 0
+    for x, y, r, g, b in fr["samples"]:
+        assert img[y, x, :3].tolist() == [r, g, b], (x, y)
+    assert zlib.crc32(img.tobytes()) & 0xFFFFFFFF == fr["crc32_rgba8_row0_bottom"]
+
+
+def _match(nodes, i, pat, binds):
+    """pattern: ("Op", sub ...) | "$name" (binds a node number; the same name must meet the same node) | a float constant"""
+    n = nodes[i]
+    if isinstance(pat, str):
+        if pat in binds:
+            return binds[pat] == i
+        binds[pat] = i
+        return True
+    if isinstance(pat, float):
+        return n[0] == "const" and n[1] == pat
+    if n[0] != pat[0] or len(n) != len(pat):
+        return False
+    return all((_match(nodes, c, p, binds) if isinstance(c, int) and not isinstance(p, int) else c == p) for c, p in zip(n[1:], pat[1:]))
+
+
+def test_the_operation_order_the_oracle_restates_is_the_spirv_binarys():
+    """What oracle/rtiow_oracle.c:174-214 (and the kernels' ch_pixel) restate, checked against the expression trees of the reference's
+    binaries instead of "read side by side by a person": b = 2 * dot(oc, dir); c = dot(oc, oc) - r * r; disc = b * b - (4 * a) * c;
+    t = (-b - sqrt(disc)) / (2 * a) behind disc < 0 -> -1; CH05 returns disc > 0; u = float(gid.x) / (imageWidth - 1);
+    normalize is the extended instruction (no hand-written division); nothing carries NoContraction; 16 x 16 x 1 workgroups."""
+    c6, c5 = _SPV["shaders"]["CH06"], _SPV["shaders"]["CH05"]
+    for sh in (c5, c6):
+        assert sh["local_size"] == [16, 16, 1]                      # raytrace06.comp:2
+        assert sh["no_contraction_decorations"] == 0                # contraction is the driver's choice: parity to +-1 LSB only
+        assert sh["float_constants"] == [-1.0, 0.0, 0.5, 0.699999988079071, 1.0, 2.0, 4.0]
+    oc = ("vec", ("FSub", "$ox", "$cx"), ("FSub", "$oy", "$cy"), ("FSub", "$oz", "$cz"))
+    b = ("FMul", 2.0, ("Dot", "$oc", "$dir"))
+    disc = ("FSub", ("FMul", "$b", "$b"), ("FMul", ("FMul", 4.0, ("Dot", "$dir", "$dir")), ("FSub", ("Dot", "$oc", "$oc"), ("FMul", "$r", "$r"))))
+    n6 = c6["expression_nodes"]
+    binds = {}
+    t = ("Select", ("FOrdLessThan", "$disc", 0.0), -1.0, ("FDiv", ("FSub", ("FNegate", "$b"), ("Sqrt", "$disc")), ("FMul", 2.0, ("Dot", "$dir", "$dir"))))
+    assert _match(n6, c6["functions"]["hitSphere"]["returns"], t, binds)
+    assert _match(n6, binds["$disc"], disc, binds) and _match(n6, binds["$b"], b, binds) and _match(n6, binds["$oc"], oc, binds)
+    assert c6["functions"]["hitSphere"]["ext_insts"] == ["Sqrt"] and c6["functions"]["rayColor"]["ext_insts"] == ["Normalize"]
+    n5 = c5["expression_nodes"]
+    binds = {}
+    assert _match(n5, c5["functions"]["hitSphere"]["returns"], ("FOrdGreaterThan", "$disc", 0.0), binds)   # raytrace05.comp:29
+    assert _match(n5, binds["$disc"], disc, binds) and _match(n5, binds["$b"], b, binds)
+    assert c5["functions"]["hitSphere"]["ext_insts"] == []
+    for sh, nodes in ((c5, n5), (c6, n6)):                          # raytrace06.comp:57-58
+        uses = [n for n in nodes if n[0] == "FDiv" and nodes[n[1]][0] == "ConvertUToF"]
+        assert len(uses) == 2
+        for n in uses:
+            den, gid = nodes[n[2]], nodes[nodes[n[1]][1]]
+            assert den[0] == "FSub" and nodes[den[1]] == ["ubo", gid[1]] and nodes[den[2]] == ["const", 1.0]
+        # the stored texel: vec4(colour, 0.0) at (gid.x, gid.y)
+        st = sh["functions"]["main"]["stores"]
+        assert nodes[nodes[st["colour"]][4]] == ["const", 0.0]
+    # CH06's hit colour is 0.5 * (N + 1) with N = normalize(orig + dir * t - (0, 0, -1)): the sky and the normal branch under t > 0
+    col = n6[c6["functions"]["rayColor"]["returns"]]
+    assert col[0] == "vec" and all(n6[k][0] == "Select" and n6[n6[k][1]][0] == "FOrdGreaterThan" for k in col[1:])
+    hit_x = n6[n6[col[1]][2]]
+    # (VectorTimesScalar: the vector's component first, then the scalar)
+    assert hit_x[0] == "FMul" and n6[hit_x[2]] == ["const", 0.5] and n6[hit_x[1]][0] == "FAdd" and n6[n6[hit_x[1]][1]][0] == "NormalizeComponent"
