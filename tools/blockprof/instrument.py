@@ -10,7 +10,7 @@ static instruction list.  The sums must reproduce the SQ_INSTS_* counters of the
 Inserted per block (wave-uniform, EXEC-independent, SCC / VCC / EXEC / M0 untouched):
     v_writelane_b32 vS, s0..s2 -> lanes 0..2      save three scalars in a spare vector register
     v_readlane_b32  s0, s1 <- vB lanes 0, 1       the counter array's address (put there by the kernel's first instructions)
-    s_mov_b32 s2, 1 ; s_atomic_add s2, s[0:1], 128 * b ; s_waitcnt lgkmcnt(0)
+    s_mov_b32 s2, 1 ; s_atomic_add s2, s[0:1], 128 * b ; s_waitcnt lgkmcnt(0)     (and one s_waitcnt lgkmcnt(0) in front of it all)
     v_readlane_b32  s0..s2 <- vS ; s_nop 4        restore (the nops: a VALU-written SGPR must age before VMEM / lane-select reads it)
 vS, vB are the two vector registers after the kernel's own (.amdhsa_next_free_vgpr is raised by two).
 
@@ -39,7 +39,9 @@ LABEL = re.compile(r"^(\.LBB\d+_\d+|_Z\w+):")
 
 
 def counter_code(b):
-    return [f"\t; ---- blockprof: block {b}",
+    # (the first wait: a scalar load still in flight may have s0..s2 as its destination -- saved before it lands and restored after, they
+    # would lose what it loaded)
+    return [f"\t; ---- blockprof: block {b}", "\ts_waitcnt lgkmcnt(0)",
             f"\tv_writelane_b32 v{vS}, s0, 0", f"\tv_writelane_b32 v{vS}, s1, 1", f"\tv_writelane_b32 v{vS}, s2, 2",
             f"\tv_readlane_b32 s0, v{vB}, 0", f"\tv_readlane_b32 s1, v{vB}, 1", "\ts_mov_b32 s2, 1", "\ts_nop 4",
             f"\ts_atomic_add s2, s[0:1], 0x{b * STRIDE:x}", "\ts_waitcnt lgkmcnt(0)",
@@ -84,4 +86,4 @@ open(dst, "w").write("\n".join(out))
 files = {int(mm.group(1)): mm.group(2) for mm in (re.match(r'\s+\.file\s+(\d+)\s+"[^"]*"\s+"([^"]*)"', l) for l in lines) if mm}
 json.dump({"files": files, "kernel": name, "stride_bytes": STRIDE, "blocks": blocks, "spare_vgprs": [vS, vB]}, open(map_path, "w"))
 n_ins = sum(len(b) for b in blocks)
-print(f"{name}: {len(blocks)} blocks, {n_ins} instructions, {len(blocks) * 13 + 8} inserted; spare registers v{vS}, v{vB}; counters need {len(blocks) * STRIDE} bytes")
+print(f"{name}: {len(blocks)} blocks, {n_ins} instructions, {len(blocks) * 14 + 8} inserted; spare registers v{vS}, v{vB}; counters need {len(blocks) * STRIDE} bytes")

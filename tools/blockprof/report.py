@@ -186,3 +186,22 @@ for line, c in sorted(by_line.items(), key=lambda kv: -kv[1]["valu"])[:n_lines]:
 print("\n(4) v_readlane / v_writelane / v_readfirstlane by basic block: executed, block entries x instructions in it, block, its regions, its source lines")
 for tot, c, n_rw, b, regs, span in sorted(rw_blocks, reverse=True)[:40]:
     print(f"    {tot:12.4g} = {c:10d} x {n_rw:3d}   block {b:4d} ({len(blocks[b]):4d} instructions)  {', '.join(f'{r} ({k})' for r, k in regs):60s} lines {span}")
+
+# --kind K: the blocks that execute most instructions of one kind (mov, cndmask, cmp, int/bit, salu ...); --block B: a block's listing
+if "--kind" in sys.argv:
+    want = sys.argv[sys.argv.index("--kind") + 1]
+    rows = []
+    for b, ins in enumerate(blocks):
+        n = sum(1 for op, rest, line in ins if classify(op, rest)[1] == want or classify(op, rest)[0] == want)
+        if n and counts[b]:
+            rows.append((n * counts[b], counts[b], n, b))
+    print(f"\n(5) '{want}' by basic block")
+    for tot, c, n, b in sorted(rows, reverse=True)[:30]:
+        regs = collections.Counter(context_regions(blocks[b])).most_common(2)
+        ls = sorted({l for _, _, l in blocks[b] if l > 0})
+        print(f"    {tot:12.4g} = {c:10d} x {n:3d}   block {b:4d} ({len(blocks[b]):4d} instructions)  {', '.join(f'{r} ({k})' for r, k in regs):60s} lines {ls[:1] + ls[-1:]}")
+if "--block" in sys.argv:
+    for b in [int(x) for x in sys.argv[sys.argv.index("--block") + 1].split(",")]:
+        print(f"\nblock {b}: entered {counts[b]} times")
+        for op, rest, line in blocks[b]:
+            print(f"    {line:6d}  {op} {rest}")

@@ -1022,6 +1022,39 @@ PersistentKernelFn small_clustered_kernel(bool flat);  // path_persistent_kernel
 PersistentKernelFn large_clustered_kernel(bool flat);  // path_persistent_kernel<false, true, flat>, from the third
 namespace {
 
+// ---- Cold kernel arguments are re-read where they are used (round 5) ----------------------------------------------------------
+// A persistent kernel holds every argument it touches in a scalar register from its first instruction to its last: the compiler
+// loads the by-value structs once (22 s_load at the top of the default kernel) and never again.  PathArgs + PersistArgs are ~100
+// dwords, the loop state another ~30, a wave has 102 SGPRs: round 4's default kernel kept 199 scalar values in VGPR lanes, and
+// tools/blockprof counted what that costs -- 3.1e8 v_readlane / v_writelane per cover frame, 6.4 % of all vector instructions
+// (profiles/r05_instruction_mix_base.txt).  Most of those arguments are COLD: the camera's 22 floats and the cone margins are used
+// once per primary pass (1.7 million a frame, ~1000 instructions each), the queue's constants once per pixel opened, the frame's
+// pointers once per batch of resolved pixels.  reload_*() reads them again from the kernel-argument segment -- scalar loads, served
+// by the scalar cache -- through a pointer the compiler cannot see through (the empty asm), so that the loads stay where they are
+// written and the values die with the stage that uses them.  `a` and `g` themselves are only to be used for what the per-segment
+// code needs (the list's shape, the boxes' range, spp, max_depth).  (Round 2 tried "the camera read from the kernel-argument segment
+// at its use" with volatile loads inside camera_path: 9.6 -> 10.25 ms; that was 22 separate dependent loads in the middle of the
+// camera code.  Here one batch of wide loads is issued at the head of a stage and waited for once.)
+typedef const __attribute__((address_space(4))) unsigned char* KernargBytes;
+DI KernargBytes kernarg_opaque() {
+    KernargBytes k = (KernargBytes)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return k;
+}
+constexpr size_t kPersistArgsOffset = (sizeof(PathArgs) + alignof(PersistArgs) - 1u) / alignof(PersistArgs) * alignof(PersistArgs);
+// (the copies come from the constant address space with their structs' alignment -- the empty asm hides the segment's -- or the loads
+// would be vector loads of the same address in every lane: s_load needs dword alignment)
+DI PathArgs reload_path_args() {  // (only the fields the caller reads are loaded: the copy is scalarised)
+    PathArgs r;
+    __builtin_memcpy(&r, (const __attribute__((address_space(4))) PathArgs*)kernarg_opaque(), sizeof(PathArgs));
+    return r;
+}
+DI PersistArgs reload_persist_args() {
+    PersistArgs r;
+    __builtin_memcpy(&r, (const __attribute__((address_space(4))) PersistArgs*)(kernarg_opaque() + kPersistArgsOffset), sizeof(PersistArgs));
+    return r;
+}
+
 DI void examine_candidate(const float4* lds, uint32_t j, uint32_t n, const Path& p, float& best,
                           int& best_i) {
     if (j >= n) return;  // list padding
@@ -2584,8 +2617,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     // wave-uniform queue state (SGPRs)
     uint32_t pool_next = 0u, pool_end = 0u;  // the wave's pool: virtual pixel indices of queue pool_xcd not yet begun
     uint32_t pool_xcd = 0u, steal = 0u;      // the queue it came from; queues found dry so far
-    const uint32_t xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;  // HW_REG_XCC_ID[3:0]
-    const uint32_t n_chunks = (g.total_pix + kChunkPix - 1u) / kChunkPix;
+    // (the XCD this wave runs on and the tile's chunk count are worked out where a pool is fetched: hand_out)
     uint32_t cur_pix = 0xFFFFFFFEu, cur_entry = 0u;  // pixel being handed out (none yet) and its accumulator entry
     uint32_t cur_col = 0u, cur_row = 0u;     // ... its column and its row of the frame
     uint32_t cur_seq = ~0u, cur_chunk = 0u;  // position in the chunk sequence the wave is in, and the chunk there
@@ -2693,6 +2725,8 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     // gathered, hand_out when it runs out of entries, the wave when it is through) and go eight and more at a time.
     auto resolve_done = [&]() {
         if (done_entries == 0ull) return;
+        const PathArgs ca = reload_path_args();  // (cold: the frame's pointers, pitch and width, the accumulators, the quantiser)
+        const uint32_t total_pix = reload_persist_args().total_pix;
         const bool mine = ((done_entries >> lane) & 1ull) != 0ull;
         bool line_full = false;  // this lane's pixel was the last of a line buffer
         uint32_t done_pix = 0u, my_line = 0u;
@@ -2702,10 +2736,10 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             done_pix = where & ((1u << kPixLineShift) - 1u);
             my_line = where >> kPixLineShift;
             const unsigned long long cost = acc[3] >> 32;  // what the pixel's samples cost (weighted segments: see shade_one)
-            const uint32_t colour = close_pixel(a, done_pix, acc[0], acc[1], acc[2]);
+            const uint32_t colour = close_pixel(ca, done_pix, acc[0], acc[1], acc[2]);
             if (my_line == 0u) {
-                const uint32_t lr = pixel_row(a, done_pix), i = done_pix - lr * a.width;
-                a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = colour;
+                const uint32_t lr = pixel_row(ca, done_pix), i = done_pix - lr * ca.width;
+                ca.dst[static_cast<size_t>(lr) * ca.dst_stride + i] = colour;
             } else {  // a pixel of a chunk this wave renders alone: into the line buffer
                 lds_line[(my_line - 1u) * kChunkPix + done_pix % kChunkPix] = colour;
                 uint32_t* meta = lds_line_meta + kLineMetaWords * (my_line - 1u);
@@ -2717,11 +2751,11 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             // memory-side request: whole chunks sum theirs in LDS and report once, with the line)
             // ... and of the pixels handed out one by one, every kCostSample-th speaks for its neighbours -- unless a long
             // path ended in this one: those are what the order is for, and too rare to be sampled
-            if (a.chunk_cost != nullptr && my_line == 0u) {
-                if (cost >= static_cast<unsigned long long>(a.spp) * kLongFrom + kLongFrom * kLongWeight)  // (one long path at least)
-                    atomicAdd(a.chunk_cost + done_pix / kChunkPix, cost);
+            if (ca.chunk_cost != nullptr && my_line == 0u) {
+                if (cost >= static_cast<unsigned long long>(ca.spp) * kLongFrom + kLongFrom * kLongWeight)  // (one long path at least)
+                    atomicAdd(ca.chunk_cost + done_pix / kChunkPix, cost);
                 else if ((done_pix & (kCostSample - 1u)) == 0u)
-                    atomicAdd(a.chunk_cost + done_pix / kChunkPix, static_cast<unsigned long long>(kCostSample) * cost);
+                    atomicAdd(ca.chunk_cost + done_pix / kChunkPix, static_cast<unsigned long long>(kCostSample) * cost);
             }
         }
         // a pixel that filled its line buffer has the line stored -- up to 32 consecutive pixels, 128 bytes, the whole line of the
@@ -2732,14 +2766,14 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             full &= full - 1ull;
             const uint32_t line = __builtin_amdgcn_readlane(my_line, l) - 1u;
             const uint32_t first = __builtin_amdgcn_readlane(done_pix, l) / kChunkPix * kChunkPix;
-            const uint32_t count = g.total_pix - first < kChunkPix ? g.total_pix - first : kChunkPix;
+            const uint32_t count = total_pix - first < kChunkPix ? total_pix - first : kChunkPix;
             if (lane < count) {
                 const uint32_t pix = first + lane;
-                const uint32_t lr = pixel_row(a, pix), i = pix - lr * a.width;  // (a chunk may run over the end of a row)
-                a.dst[static_cast<size_t>(lr) * a.dst_stride + i] = lds_line[line * kChunkPix + lane];
+                const uint32_t lr = pixel_row(ca, pix), i = pix - lr * ca.width;  // (a chunk may run over the end of a row)
+                ca.dst[static_cast<size_t>(lr) * ca.dst_stride + i] = lds_line[line * kChunkPix + lane];
             }
-            if (a.chunk_cost != nullptr && lane == 0u)  // this wave rendered the whole chunk: a plain store
-                a.chunk_cost[first / kChunkPix] = *reinterpret_cast<const unsigned long long*>(lds_line_meta + kLineMetaWords * line + 2u);
+            if (ca.chunk_cost != nullptr && lane == 0u)  // this wave rendered the whole chunk: a plain store
+                ca.chunk_cost[first / kChunkPix] = *reinterpret_cast<const unsigned long long*>(lds_line_meta + kLineMetaWords * line + 2u);
             free_lines |= 1u << line;
         }
         free_entries |= done_entries;  // the entries return to the wave
@@ -2757,7 +2791,12 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             uint32_t served = 0u;  // wave-uniform
             while (served < want) {  // one trip per pixel touched (1-2 unless spp is tiny)
                 if (cur_s == a.spp) {  // open the next pixel of the pool
+                    // (cold: the queue's constants, the tile's shape, the chunk order -- read once per pixel opened)
+                    const PathArgs ca = reload_path_args();
+                    const PersistArgs cg = reload_persist_args();
+                    const uint32_t n_chunks = (cg.total_pix + kChunkPix - 1u) / kChunkPix;
                     if (pool_next == pool_end) {
+                        const uint32_t xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;  // HW_REG_XCC_ID[3:0]
                         // Pool fetch.  The tile's pixels are cut into chunks of kChunkPix consecutive pixels dealt
                         // round-robin to eight queues, one per XCD: a wave draws from the queue of the XCD it runs
                         // on, so the 4-byte stores that complete a 128-byte line of the frame all come from one L2
@@ -2775,21 +2814,21 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                             // LDS and writes it with one store.  That part has a head of its own and a fetch is one atomic add, no
                             // look at the head first (a look and an add are 64 bytes of fabric traffic each: with one queue for
                             // everything the looks alone were 1.9 MB per cover frame, half of what the frame itself weighs).
-                            const uint32_t wsize = vsize > g.chunk_until ? (vsize - g.chunk_until) / g.chunk_pool * g.chunk_pool : 0u;
+                            const uint32_t wsize = vsize > cg.chunk_until ? (vsize - cg.chunk_until) / cg.chunk_pool * cg.chunk_pool : 0u;
                             if (wsize != 0u && ((whole_done >> xq) & 1u) == 0u) {
                                 uint32_t got = 0u;
-                                if (lane == 0u) got = atomicAdd(&a.counters->xcd_chunk[xq].next, g.chunk_pool);
+                                if (lane == 0u) got = atomicAdd(&ca.counters->xcd_chunk[xq].next, cg.chunk_pool);
                                 got = __builtin_amdgcn_readfirstlane(got);
                                 if (got < wsize) {
                                     pool_next = got;
-                                    pool_end = got + g.chunk_pool;  // (<= wsize: both are multiples of the pool)
+                                    pool_end = got + cg.chunk_pool;  // (<= wsize: both are multiples of the pool)
                                     pool_xcd = xq;
                                     pool_owned = true;
                                     fetched = true;
 #ifdef RTIOW_DEBUG_TIMELINE
-                                    if (xq == 0u && lane == 0u && got * 8u / vsize != (got + g.chunk_pool) * 8u / vsize) {
+                                    if (xq == 0u && lane == 0u && got * 8u / vsize != (got + cg.chunk_pool) * 8u / vsize) {
                                         const unsigned long long t0w = ~__hip_atomic_load(&a.counters->not_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                        a.counters->tl_progress[(got + g.chunk_pool) * 8u / vsize] = static_cast<unsigned int>(wall_clock64() - t0w);
+                                        a.counters->tl_progress[(got + cg.chunk_pool) * 8u / vsize] = static_cast<unsigned int>(wall_clock64() - t0w);
                                     }
 #endif
                                     break;
@@ -2810,11 +2849,11 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                                 // frame, tile 5: 1.60 ms with pools of 4, 2.0 with 8, 1.36 with 1; tools/tile_ranks.py).  So the first
                                 // g.fine_until pixels of a queue go out an iteration's worth of samples at a time -- one pixel at 100 spp
                                 // (judged by the wave's last fetch: no look at the head).
-                                const uint32_t k = pool_fine ? g.fine_pix : g.pool_pix;
+                                const uint32_t k = pool_fine ? cg.fine_pix : cg.pool_pix;
                                 uint32_t got = 0u;
-                                if (lane == 0u) got = atomicAdd(&a.counters->xcd_head[xq].next, k);
+                                if (lane == 0u) got = atomicAdd(&ca.counters->xcd_head[xq].next, k);
                                 got = __builtin_amdgcn_readfirstlane(got);
-                                pool_fine = wsize + got + k < g.fine_until;
+                                pool_fine = wsize + got + k < cg.fine_until;
 #ifdef RTIOW_DEBUG_TIMELINE
                                 if (xq == 0u && lane == 0u && got < rest && (wsize + got) * 8u / vsize != (wsize + got + k) * 8u / vsize) {
                                     const unsigned long long t0w = ~__hip_atomic_load(&a.counters->not_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2853,8 +2892,8 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     if (seq != cur_seq) {  // (wave-uniform: one scalar load per chunk entered)
                         cur_seq = seq;
                         // (the order is stored queue by queue, so that an XCD reads its own eighth of it and no more)
-                        cur_chunk = a.chunk_order != nullptr
-                                        ? __builtin_amdgcn_readfirstlane(a.chunk_order[chunk_order_slot(seq, n_chunks)])
+                        cur_chunk = ca.chunk_order != nullptr
+                                        ? __builtin_amdgcn_readfirstlane(ca.chunk_order[chunk_order_slot(seq, n_chunks)])
                                         : seq;
                         cur_line = 0u;
                         if (pool_owned && free_lines != 0u) {  // (no buffer free: this chunk's pixels go straight to the frame)
@@ -2862,12 +2901,12 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                             free_lines &= free_lines - 1u;
                             cur_line = line + 1u;
                             const uint32_t first = cur_chunk * kChunkPix;
-                            const uint32_t expect = g.total_pix - first < kChunkPix ? g.total_pix - first : kChunkPix;  // ragged last chunk
+                            const uint32_t expect = cg.total_pix - first < kChunkPix ? cg.total_pix - first : kChunkPix;  // ragged last chunk
                             if (lane < kLineMetaWords) lds_line_meta[kLineMetaWords * line + lane] = lane == 1u ? expect : 0u;
                         }
                     }
                     const uint32_t pix = cur_chunk * kChunkPix + pool_next % kChunkPix;
-                    if (pix >= g.total_pix) {  // the ragged end of the last chunk
+                    if (pix >= cg.total_pix) {  // the ragged end of the last chunk
                         ++pool_next;
                         continue;
                     }
@@ -2882,12 +2921,12 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     free_entries &= free_entries - 1ull;
                     // column and row (of the frame) of the pixel: by one division for the first pixel of a pool or a row, by counting
                     // for those that follow it (rounds 1-3: two or three divisions per lane and pass, a dozen instructions each)
-                    if (pix == cur_pix + 1u && cur_col + 1u < a.width) {
+                    if (pix == cur_pix + 1u && cur_col + 1u < ca.width) {
                         ++cur_col;
                     } else {
-                        const uint32_t lr = pixel_row(a, pix);
-                        cur_col = pix - lr * a.width;
-                        cur_row = tile_global_row(a, lr);
+                        const uint32_t lr = pixel_row(ca, pix);
+                        cur_col = pix - lr * ca.width;
+                        cur_row = tile_global_row(ca, lr);
                     }
                     cur_pix = pix;
                     ++pool_next;
@@ -2959,20 +2998,26 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                         return true;
                     });
                     if (granted == 0u) break;  // queues dry, or all accumulator entries in use (then paths are in flight)
+                    // (cold: the camera, the frame's size and seed, the cone test's margins -- read once per pass; what the per-segment code
+                    // keeps in registers anyway comes from there)
+                    PathArgs pa = reload_path_args();
+                    pa.n_large = a.n_large; pa.n_large_slots = a.n_large_slots; pa.n_clusters = a.n_clusters; pa.n_super = a.n_super;
+                    pa.flat_axis = a.flat_axis; pa.flat_mid = a.flat_mid; pa.flat_half = a.flat_half;
+                    const PersistArgs pg = reload_persist_args();
                     [[maybe_unused]] const unsigned long long tp0 = DBG_STAMP();
                     DBG_ADD(dbg_pass[0], lane == 0u ? 1u : 0u);
                     DBG_ADD(dbg_pass[6], lane == 0u ? tp0 - th0 : 0ull);  // hand_out
                     DBG_ADD(dbg_pass[1], lane == 0u ? granted : 0u);
                     ps.active = lane < granted;
                     if (ps.active) {
-                        camera_path(a, gen_col, gen_row, a.sample_offset + gen_s, ps.p);
+                        camera_path(pa, gen_col, gen_row, pa.sample_offset + gen_s, ps.p);
                         ++n_paths;
                     }
                     DBG_ADD(dbg_pass[7], lane == 0u ? DBG_STAMP() - tp0 : 0ull);  // camera_path
                     float pb;
                     int pb_i;
                     uint32_t pb_o;
-                    primary_trace<!SHADE_LDS, FLAT>(lds_spheres, lds_cidx, lds_cbounds, a, g, ps.p, ps.active, span_col, span_len, span_row, n_spans,
+                    primary_trace<!SHADE_LDS, FLAT>(lds_spheres, lds_cidx, lds_cbounds, pa, pg, ps.p, ps.active, span_col, span_len, span_row, n_spans,
                                               pb, pb_i, pb_o, n_tests, dbg_pass[2]);
                     float4 pr0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pr1 = pr0;
                     if (!SHADE_LDS && ps.active && pb_i >= 0) {
@@ -3060,7 +3105,8 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     float4* rec = scratch4;  // [64] {o, d.x} then [64] {d.y, d.z, rng, -}
                     if (lane < granted) {
                         Path np;
-                        camera_path(a, gen_col, gen_row, a.sample_offset + gen_s, np);
+                        const PathArgs pa = reload_path_args();  // (cold: the camera)
+                        camera_path(pa, gen_col, gen_row, pa.sample_offset + gen_s, np);
                         rec[lane] = make_float4(np.o.x, np.o.y, np.o.z, np.du.x);
                         rec[64u + lane] = make_float4(np.du.y, np.du.z, __uint_as_float(np.rng.state), 0.0f);
                     }
@@ -3102,7 +3148,8 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     return true;
                 });
                 if (got_sample) {  // start the sample
-                    camera_path(a, my_col, my_row, a.sample_offset + my_s, q.p);
+                    const PathArgs pa = reload_path_args();  // (cold: the camera)
+                    camera_path(pa, my_col, my_row, pa.sample_offset + my_s, q.p);
                     q.active = true;
                     ++n_paths;
                 }
@@ -3287,6 +3334,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     // One counter update per WORKGROUP: the waves sum in LDS as they leave, the last one out adds the sums to the global
     // counters (a global atomic is a 64-byte memory-side request: three per wave were 0.6 MB per frame).  A wave's sums
     // reach LDS before its arrival tick (its LDS operations are performed in order), so the last arrival sees them all.
+    const PathArgs ea = reload_path_args();  // (cold: the counter blocks)
     unsigned long long tests64 = n_tests;
     bool last_group = false;
     for (int off = 32; off > 0; off >>= 1) {
@@ -3301,22 +3349,22 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         // (release / acquire at workgroup scope on the arrival tick, and atomic reads of the sums: the ordering the last
         // wave relies on is in the code, not in how the LDS happens to execute a wave's operations)
         if (__hip_atomic_fetch_add(&wg_left, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u == waves_in_group) {
-            atomicAdd(&a.counters->paths, __hip_atomic_load(&wg_sums[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            atomicAdd(&a.counters->segments, __hip_atomic_load(&wg_sums[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            atomicAdd(&a.counters->tests, __hip_atomic_load(&wg_sums[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            atomicAdd(&ea.counters->paths, __hip_atomic_load(&wg_sums[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            atomicAdd(&ea.counters->segments, __hip_atomic_load(&wg_sums[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            atomicAdd(&ea.counters->tests, __hip_atomic_load(&wg_sums[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             // the last workgroup out zeroes the counter block of the NEXT frame (queue heads and all): the frames of a
             // loop then follow each other without a memset in between (with the stats copy moved to rtGetStats, the gap
             // between two path kernels went from 34 to ~10 us)
-            last_group = __hip_atomic_fetch_add(&a.counters->wg_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x;
+            last_group = __hip_atomic_fetch_add(&ea.counters->wg_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x;
         }
     }
     if (blockIdx.x == 0u && threadIdx.x == 0u) {  // (its own stamps: written by this very lane)
-        a.counters->clk_cycles = __builtin_readcyclecounter() - clk_start[0];  // (rtGetStats divides)
-        a.counters->clk_ticks = wall_clock64() - clk_start[1];
+        ea.counters->clk_cycles = __builtin_readcyclecounter() - clk_start[0];  // (rtGetStats divides)
+        ea.counters->clk_ticks = wall_clock64() - clk_start[1];
     }
     last_group = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(last_group)) != 0u;
-    if (last_group && a.next_counters != nullptr) {
-        uint32_t* words = reinterpret_cast<uint32_t*>(a.next_counters);
+    if (last_group && ea.next_counters != nullptr) {
+        uint32_t* words = reinterpret_cast<uint32_t*>(ea.next_counters);
         for (uint32_t k = lane; k < sizeof(Counters) / 4u; k += 64u) words[k] = 0u;
     }
 #ifdef RTIOW_DEBUG_COUNTERS
