@@ -174,7 +174,8 @@ constexpr uint32_t kWavePixBytes = kAccEntries * 4u;              // ... and the
 constexpr uint32_t kItemCap = 512;                   // (clustered) items per work list
 constexpr uint32_t kWaveResultBytes = 128u * 8u;     // (clustered) one u64 key per path slot of the wave
 __host__ __device__ constexpr uint32_t wave_item_bytes(bool two_level) { return kWaveResultBytes + kItemCap * 2u * (two_level ? 2u : 1u); }
-constexpr size_t kLdsPerCu = 160u * 1024u - 256u;    // (the kernels' static __shared__ words come on top of the dynamic part)
+constexpr size_t kLdsPerCu = 160u * 1024u - 192u;    // dynamic LDS a workgroup of the persistent kernels may ask for (they have no static __shared__)
+constexpr uint32_t kGroupLdsBytes = 64u;             // ... of which the workgroup's own words: the leaving waves' sums and tick, one wave's clock stamps
 // kernel variants selectable through RtParams.kernel (identical results)
 struct ClusterF4 {
     float x, y, z, w;
@@ -212,7 +213,7 @@ inline int clustered_levels_that_fit(uint32_t n_cslots, uint32_t n_clusters, uin
     const uint32_t box_bytes = flat ? 16u : 32u;
     auto fits = [&](uint32_t supers) {
         return static_cast<size_t>(n_cslots) * 20u + static_cast<size_t>(n_clusters + supers) * box_bytes +
-                   4u * (kWaveAccBytes + kWavePixBytes + kWaveLineBytes + wave_item_bytes(supers != 0u)) <= kLdsPerCu;
+                   kGroupLdsBytes + 4u * (kWaveAccBytes + kWavePixBytes + kWaveLineBytes + wave_item_bytes(supers != 0u)) <= kLdsPerCu;
     };
     return fits(n_super) ? 2 : (fits(0u) ? 1 : 0);
 }

@@ -1249,13 +1249,18 @@ DI void examine_cluster(const float4* slots, const uint32_t* idx_map, uint32_t b
     // sixteen lane constants, which the compiler kept in sixteen registers all kernel long; this one is one XOR with an immediate on
     // the item's own number (`base` is a multiple of 16: the large spheres' slots are padded to whole clusters).
     const uint32_t first = base + (lane & (kClusterSize - 1u));
+    // (round 5: the XOR is taken on the BYTE offset, hidden from the compiler, which otherwise turns (first << 4) ^ (k << 4) back into
+    // (first ^ k) << 4 -- an XOR and a shift per member, 32 instructions a round where 15 XORs do: tools/blockprof, block of line 1258)
+    uint32_t first_bytes = first * static_cast<uint32_t>(sizeof(float4));
+    asm volatile("" : "+v"(first_bytes));
     // four members per step, their reads issued together (left to itself the compiler keeps two reads in flight and
     // waits for each after eleven instructions; an LDS read with per-lane addresses takes longer than that)
 #pragma unroll
     for (uint32_t k0 = 0; k0 < kClusterSize; k0 += 4u) {
         float4 s4[4];
 #pragma unroll
-        for (uint32_t u = 0; u < 4u; ++u) s4[u] = slots[first ^ (k0 + u)];
+        for (uint32_t u = 0; u < 4u; ++u)
+            s4[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(slots) + (first_bytes ^ ((k0 + u) * static_cast<uint32_t>(sizeof(float4)))));
 #pragma unroll
         for (uint32_t u = 0; u < 4u; ++u) {
             const float4 s = s4[u];
@@ -2554,19 +2559,13 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     // (small scenes only: the large-scene variant, at its 168 registers, spills two of them with the second copy of the
     // sparse trace, and the end of its frames -- seconds long -- does not matter)
     constexpr bool kSparseLoop = RTIOW_TAIL_LOOP != 0 && ACCEL && SHADE_LDS;
+    // (No static __shared__ variable in this kernel: the dynamic area then starts at LDS address 0 and every address in it is a pure
+    // offset -- the member reads of examine_cluster XOR a lane's byte offset with k * 16 and need no base added.  The workgroup's few
+    // words of its own live in the dynamic area too, kGroupLdsBytes in front of the per-wave areas.)
     extern __shared__ float4 lds_spheres[];
-    __shared__ unsigned long long wg_sums[3];  // paths, segments, tests of the waves that have left
-    __shared__ unsigned int wg_left;           // how many have
-    if (threadIdx.x < 3u) wg_sums[threadIdx.x] = 0ull;
-    if (threadIdx.x == 3u) wg_left = 0u;
     // The shader clock this frame ran at, from one wave's two clocks (shader cycles, and the constant 100 MHz counter): the stamps
     // are parked in LDS, not in registers.  (The fp32 peak a frame can be rated against is 157.3 TFLOP/s at 2.4 GHz;
     // under this kernel the part holds about 2.0: bench.py prints both.)
-    __shared__ unsigned long long clk_start[2];
-    if (threadIdx.x == 0u) {
-        clk_start[0] = __builtin_readcyclecounter();
-        clk_start[1] = wall_clock64();
-    }
     uint32_t* lds_cidx = reinterpret_cast<uint32_t*>(lds_spheres + g.n_pad);
     float4* lds_cbounds = reinterpret_cast<float4*>(lds_cidx + (ACCEL ? g.n_pad : 0u));
     // (boxes: centre + half extent, two float4 each; FLAT: without the flat axis, one float4 each)
@@ -2577,7 +2576,17 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     // from ONE base.  (Rounds 1-3 laid every one of these out as an array over the workgroup's waves: seven base addresses to hold.)
     const uint32_t waves_in_group = blockDim.x / 64u;
     const uint32_t wave_in_group = threadIdx.x / 64u;
-    unsigned char* lds_wave = reinterpret_cast<unsigned char*>(lds_shade + (SHADE_LDS ? 2u * a.n : 0u)) + wave_in_group * g.wave_bytes;
+    unsigned char* lds_group = reinterpret_cast<unsigned char*>(lds_shade + (SHADE_LDS ? 2u * a.n : 0u));
+    unsigned long long* wg_sums = reinterpret_cast<unsigned long long*>(lds_group);  // [3] paths, segments, tests of the waves that have left
+    unsigned int* wg_left_p = reinterpret_cast<unsigned int*>(lds_group + 24);       // how many have
+    unsigned long long* clk_start = reinterpret_cast<unsigned long long*>(lds_group + 32);  // [2] one wave's two clocks at its start
+    if (threadIdx.x < 3u) wg_sums[threadIdx.x] = 0ull;
+    if (threadIdx.x == 3u) *wg_left_p = 0u;
+    if (threadIdx.x == 0u) {
+        clk_start[0] = __builtin_readcyclecounter();
+        clk_start[1] = wall_clock64();
+    }
+    unsigned char* lds_wave = lds_group + kGroupLdsBytes + wave_in_group * g.wave_bytes;
     unsigned long long* lds_acc = reinterpret_cast<unsigned long long*>(lds_wave);
     uint32_t* lds_pix = reinterpret_cast<uint32_t*>(lds_wave + kWaveAccBytes);
     uint32_t* lds_line = reinterpret_cast<uint32_t*>(lds_wave + kWaveAccBytes + kWavePixBytes);
@@ -2662,7 +2671,10 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     // pixel's accumulator, hit -> scatter; a path that ends bumps its pixel's counter, the lane that completes a pixel
     // resolves and stores it.  r0, r1: the hit's shading record when the records are not in LDS.
     auto shade_one = [&](Slot& q, float hit_t, int hit_slot, uint32_t hit_orig, const float4& r0, const float4& r1) {
-        if (__ballot(q.active) == 0ull) return;  // (sparse iterations keep their paths in slot 0)
+#ifndef RTIOW_SHADE_EARLY_OUT
+#define RTIOW_SHADE_EARLY_OUT 1  // (-DRTIOW_SHADE_EARLY_OUT=0: A/B only)
+#endif
+        if (RTIOW_SHADE_EARLY_OUT && __ballot(q.active) == 0ull) return;  // (sparse iterations keep their paths in slot 0)
         bool finished = false;
         if (q.active) {
             ++n_segments;
@@ -3167,6 +3179,16 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         }
 #endif
         [[maybe_unused]] const unsigned long long t1 = DBG_STAMP();
+#ifndef RTIOW_DEEP_PRIO_FROM
+#define RTIOW_DEEP_PRIO_FROM 0  // (A/B: segments from which a path makes its wave's instructions win the SIMD's issue arbitration; 0: off)
+#endif
+        if constexpr (RTIOW_DEEP_PRIO_FROM != 0) {
+            // a wave that carries a long path is on the frame's critical path -- what ends a small frame is the
+            // lifetime of its fifty-bounce paths, one bounce per iteration of their wave -- so it issues ahead of its SIMD's other waves
+            const bool deep = (sl[0].active && meta_depth(sl[0].meta) >= RTIOW_DEEP_PRIO_FROM) ||
+                              (sl[kSlots - 1].active && meta_depth(sl[kSlots - 1].meta) >= RTIOW_DEEP_PRIO_FROM);
+            if (__ballot(deep) != 0ull) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+        }
 
         // ---- trace ----------------------------------------------------------
         float best[kSlots];
@@ -3348,7 +3370,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         atomicAdd(&wg_sums[2], tests64);
         // (release / acquire at workgroup scope on the arrival tick, and atomic reads of the sums: the ordering the last
         // wave relies on is in the code, not in how the LDS happens to execute a wave's operations)
-        if (__hip_atomic_fetch_add(&wg_left, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u == waves_in_group) {
+        if (__hip_atomic_fetch_add(wg_left_p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u == waves_in_group) {
             atomicAdd(&ea.counters->paths, __hip_atomic_load(&wg_sums[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             atomicAdd(&ea.counters->segments, __hip_atomic_load(&wg_sums[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             atomicAdd(&ea.counters->tests, __hip_atomic_load(&wg_sums[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -3781,7 +3803,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
         if (pass == 1 && (!accel || keep_env == 0u)) break;  // (nothing new to try)
         for (uint32_t t = 256u; t <= t_max; t += 256u) {
             if (pinned != 0u && t != pinned) continue;
-            const size_t need = lds_scene + static_cast<size_t>(t / 64u) * wave_bytes(keep);
+            const size_t need = lds_scene + kGroupLdsBytes + static_cast<size_t>(t / 64u) * wave_bytes(keep);
             if (need > kLdsPerCu) continue;
             int blocks = 0;
             e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel_fn, static_cast<int>(t), need);
