@@ -168,6 +168,7 @@ constexpr uint32_t kLineBufs = 4;                    // whole chunks a wave may 
 constexpr uint32_t kLineMetaWords = 4;               // ... {pixels done, pixels expected, segments they took (u64)}
 constexpr uint32_t kWaveLineBytes = kLineBufs * (kChunkPix + kLineMetaWords) * 4u;
 constexpr uint32_t kAccEntries = 64;                 // pixels a wave may have in flight
+constexpr uint32_t kAccEntriesCompact = 32, kLineBufsCompact = 2;  // ... and line buffers, in the compact per-wave area (large scenes at four waves per SIMD: rtiow_kernels.hip, COMPACT)
 constexpr uint32_t kAccWords = 4;                    // u64 words per entry: r, g, b, samples done
 constexpr uint32_t kWaveAccBytes = kAccEntries * kAccWords * 8u;  // 2 KiB of LDS per wave
 constexpr uint32_t kWavePixBytes = kAccEntries * 4u;              // ... and the pixel of each entry

@@ -998,7 +998,7 @@ struct Slot {
 
 }  // namespace (PersistArgs is shared with the second compilation of this file: see the end of it)
 struct PersistArgs {
-    uint32_t n_pad;        // sphere list padded to a multiple of kBlockSph
+    uint32_t n_pad;        // slots of the LDS sphere list: the flat list padded to a multiple of four, or the clustered list's slots
     uint32_t total_pix;    // pixels of this tile (the global queue counts pixels)
     uint32_t total_waves;  // waves of the grid
     uint32_t pool_pix;     // pixels per pool away from the tail
@@ -1103,8 +1103,11 @@ DI void trace_slots(const float4* lds, uint32_t n_pad, uint32_t n, Slot (&sl)[R]
         uint32_t miss[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) miss[r] = 0u;
+        // (the list is padded to a multiple of FOUR, not of the candidate word's 32: round 5 -- BASELINE config 2's four spheres took 32
+        // tests per ray and slot, 41 % of that frame's vector instructions for padding)
+        const uint32_t jn = n_pad - base < kBlockSph ? n_pad - base : kBlockSph;
 #pragma unroll 4
-        for (uint32_t j = 0; j < kBlockSph; ++j) {
+        for (uint32_t j = 0; j < jn; ++j) {
             const float4 s = lds[base + j];  // wave-uniform address: LDS broadcast
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -1120,7 +1123,7 @@ DI void trace_slots(const float4* lds, uint32_t n_pad, uint32_t n, Slot (&sl)[R]
         [[maybe_unused]] const unsigned long long ts0 = DBG_STAMP();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            uint32_t cand = sl[r].active ? ~miss[r] : 0u;
+            uint32_t cand = sl[r].active ? ~miss[r] << (kBlockSph - jn) : 0u;  // first sphere of the block at bit 31
             DBG_ADD(dbg_cands, __builtin_popcount(cand));
 #ifdef RTIOW_DEBUG_COUNTERS
             {  // wave-level trip count of the loop below = max over lanes of popcount
@@ -2520,6 +2523,9 @@ DI void primary_trace(const float4* slots, const uint32_t* idx_map, const float4
 #define RTIOW_SMALL_WAVES_PER_EU 1  // (this compilation: no constraint.  The Makefile's second pass over this file, which makes the
                                     // small-scene clustered variants that are actually launched, sets 4: see the end of the file)
 #endif
+#ifndef RTIOW_LARGE_WAVES_PER_EU
+#define RTIOW_LARGE_WAVES_PER_EU 3  // (4: A/B only -- what a fourth wave per SIMD would cost the large-scene variants in spilled registers)
+#endif
 #ifndef RTIOW_ACCEL_MAX_THREADS
 #define RTIOW_ACCEL_MAX_THREADS 768
 #endif
@@ -2548,10 +2554,18 @@ constexpr int kAccelMaxThreads = RTIOW_ACCEL_MAX_THREADS;
 #endif
 // FLAT (clustered kernels): the scene's cluster boxes share one interval along a.flat_axis, and the lock-step box tests
 // leave that axis out (slab_gap_flat).
-template <bool SHADE_LDS, bool ACCEL, bool FLAT = false>
-__global__ __launch_bounds__(ACCEL ? (SHADE_LDS ? RTIOW_SMALL_MAX_THREADS : kAccelMaxThreads) : 1024) __attribute__((amdgpu_waves_per_eu(ACCEL && !SHADE_LDS ? 3 : RTIOW_SMALL_WAVES_PER_EU)))
+// COMPACT (round 5; large-scene clustered kernels only): FOUR waves per SIMD -- one group of 1024 threads at 128 registers -- around a scene
+// whose lists leave 4.6 KB of LDS per wave instead of 5.9 (C5: 87 KB of lists): 32 accumulator entries and two line buffers per wave.
+// Round 4 could not build it: at 128 registers the variant spilled 115 of them.  With the cold arguments out of the scalar registers
+// (reload_path_args) it spills four under the default scheduler -- which is why these instantiations live in the whole-file compilation
+// pass, not in the large-scene variants' own (iterative-ilp spills 44 at 128).
+template <bool SHADE_LDS, bool ACCEL, bool FLAT = false, bool COMPACT = false>
+__global__ __launch_bounds__(COMPACT ? 1024 : (ACCEL ? (SHADE_LDS ? RTIOW_SMALL_MAX_THREADS : kAccelMaxThreads) : 1024)) __attribute__((amdgpu_waves_per_eu(COMPACT ? 4 : (ACCEL && !SHADE_LDS ? RTIOW_LARGE_WAVES_PER_EU : RTIOW_SMALL_WAVES_PER_EU))))
 void path_persistent_kernel(PathArgs a, PersistArgs g) {
     static_assert(ACCEL || !FLAT, "only the clustered list has boxes");
+    static_assert(!COMPACT || (ACCEL && !SHADE_LDS), "the compact per-wave area is for the large-scene clustered kernels");
+    constexpr uint32_t kAccE = COMPACT ? kAccEntriesCompact : kAccEntries, kLineB = COMPACT ? kLineBufsCompact : kLineBufs;
+    constexpr uint32_t kAccBytes = kAccE * kAccWords * 8u, kPixBytes = kAccE * 4u, kLineBytes = kLineB * (kChunkPix + kLineMetaWords) * 4u;
     // LDS: sphere list [g.n_pad float4] — the flat list, or (ACCEL) the clustered list's slots, then
     // (ACCEL) the slots' original indices [g.n_pad u32] and the boxes [2 (a.n_clusters + a.n_super) float4];
     // then (SHADE_LDS) two float4 of shading record per sphere; then the accumulator entries of every
@@ -2588,10 +2602,10 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     }
     unsigned char* lds_wave = lds_group + kGroupLdsBytes + wave_in_group * g.wave_bytes;
     unsigned long long* lds_acc = reinterpret_cast<unsigned long long*>(lds_wave);
-    uint32_t* lds_pix = reinterpret_cast<uint32_t*>(lds_wave + kWaveAccBytes);
-    uint32_t* lds_line = reinterpret_cast<uint32_t*>(lds_wave + kWaveAccBytes + kWavePixBytes);
-    uint32_t* lds_line_meta = lds_line + kLineBufs * kChunkPix;  // per buffer {pixels done, pixels expected, cost (u64)}
-    [[maybe_unused]] unsigned long long* lds_results = reinterpret_cast<unsigned long long*>(lds_wave + kWaveAccBytes + kWavePixBytes + kWaveLineBytes);
+    uint32_t* lds_pix = reinterpret_cast<uint32_t*>(lds_wave + kAccBytes);
+    uint32_t* lds_line = reinterpret_cast<uint32_t*>(lds_wave + kAccBytes + kPixBytes);
+    uint32_t* lds_line_meta = lds_line + kLineB * kChunkPix;  // per buffer {pixels done, pixels expected, cost (u64)}
+    [[maybe_unused]] unsigned long long* lds_results = reinterpret_cast<unsigned long long*>(lds_wave + kAccBytes + kPixBytes + kLineBytes);
     [[maybe_unused]] uint16_t* lds_items = reinterpret_cast<uint16_t*>(lds_results + 128);
     // (the small-scene variants never have super-clusters: their records sit at a fixed offset too)
     [[maybe_unused]] float4* lds_pbuf = reinterpret_cast<float4*>(
@@ -2631,9 +2645,9 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     uint32_t cur_col = 0u, cur_row = 0u;     // ... its column and its row of the frame
     uint32_t cur_seq = ~0u, cur_chunk = 0u;  // position in the chunk sequence the wave is in, and the chunk there
     uint32_t cur_s = a.spp;                  // its next sample; == spp: no pixel open
-    unsigned long long free_entries = ~0ull; // accumulator entries not in use
+    unsigned long long free_entries = kAccE == 64u ? ~0ull : (1ull << (kAccE & 63u)) - 1ull;  // accumulator entries not in use
     unsigned long long done_entries = 0ull;  // ... entries whose pixel has all its samples and waits to be resolved (resolve_done)
-    uint32_t free_lines = (1u << kLineBufs) - 1u;  // line buffers not in use
+    uint32_t free_lines = (1u << kLineB) - 1u;  // line buffers not in use
     uint32_t whole_done = 0u;                // bit q: the whole-chunk part of queue q is known to be handed out
     uint32_t rest_done = 0u;                 // ... and the rest of it
     bool pool_owned = false;                 // the pool is whole chunks of the frame that only this wave renders
@@ -3208,6 +3222,12 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 break;
             }
         }
+        if constexpr (!ACCEL) {
+            // The end of a frame with the flat list (round 5): once the queues are dry and few paths live, they are gathered in slot 0, so
+            // that the shade code runs once an iteration instead of twice (its second pass finds no path and leaves at once).  BASELINE config
+            // 2 -- 400 x 225, 0.5 ms -- is a third tail: every wave ends on the fifty bounces of a path inside the glass ball.
+            if (exhausted && live_paths <= 32u) compact_to_slot0(sl, reinterpret_cast<uint32_t*>(lds_results));
+        }
         if (ACCEL && live_paths <= kSparseMaxAccel) {
             // few paths left: gather them in slot 0 (the shade and refill code below then runs once, not
             // once per slot), then trace them together
@@ -3227,7 +3247,9 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                 dbg_sp_paths += live_paths;
             }
 #endif
-        } else if (!ACCEL && live_paths <= kSparseMax) {
+        } else if (!ACCEL && live_paths <= kSparseMax && live_paths * 3u <= g.n_pad) {
+            // (the sphere-parallel trace costs ~60 instructions a path whatever the list, the lock-step pass 22 a sphere for all 128 slots:
+            // with a handful of spheres -- BASELINE config 2 has four -- the lock-step pass is the cheaper one even for a single path)
             trace_sparse<kSlots>(lds_spheres, nullptr, g.n_pad, a.n, sl, best, best_i, best_o);
 #pragma unroll
             for (int r = 0; r < kSlots; ++r)
@@ -3754,7 +3776,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     *resolved = accel ? KERNEL_CLUSTERED : KERNEL_PERSISTENT;
     PersistArgs g{};
     // slots of the LDS sphere list: the flat list padded to whole candidate words, or the clustered one
-    g.n_pad = accel ? a.n_cslots : (a.n + kBlockSph - 1u) / kBlockSph * kBlockSph;
+    g.n_pad = accel ? a.n_cslots : (a.n + 3u) / 4u * 4u;
     (void)max_take;  // scheduling is per sample now; the hint is accepted and ignored
     g.total_pix = a.local_rows * a.width;
     // tests a segment costs, roughly: the whole list, or large spheres + boxes (14 of 11 instructions)
@@ -3779,13 +3801,25 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // the clustered kernels' primary pass keeps up to pass_keep camera paths per wave in LDS records of their own; a
     // large scene with no room for them (C5: one 768-thread group beside 92 KB of list) does without -- its passes then
     // make no more paths than there are idle slots, and the records sit in the two-level work-list area alone
-    auto wave_bytes = [&](uint32_t keep) { return kWaveAccBytes + kWavePixBytes + kWaveLineBytes + (accel ? item_bytes + keep * kPassRecBytes : 0u); };
+    // (flat list: 2 KiB of scratch for gathering a wave's last paths in one slot, compact_to_slot0)
+    auto wave_bytes_of = [&](uint32_t keep, bool compact) {
+        const uint32_t acc_e = compact ? kAccEntriesCompact : kAccEntries, line_b = compact ? kLineBufsCompact : kLineBufs;
+        return acc_e * kAccWords * 8u + acc_e * 4u + line_b * (kChunkPix + kLineMetaWords) * 4u + (accel ? item_bytes + keep * kPassRecBytes : 32u * 64u);
+    };
     void (*kernel_fn)(PathArgs, PersistArgs) =
         accel ? (shade_lds ? small_clustered_kernel(flat) : large_clustered_kernel(flat))
               : (shade_lds ? path_persistent_kernel<true, false> : path_persistent_kernel<false, false>);
+    // (large scenes: the same kernel with the compact per-wave area, four waves per SIMD -- taken when that keeps more waves on a CU)
+    void (*compact_fn)(PathArgs, PersistArgs) = nullptr;
+    if (accel && !shade_lds && !debug_knob("RTIOW_DEBUG_NO_COMPACT"))
+        compact_fn = flat ? path_persistent_kernel<false, true, true, true> : path_persistent_kernel<false, true, false, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsPerCu));
     if (e != hipSuccess) return e;
+    if (compact_fn != nullptr) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(compact_fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsPerCu));
+        if (e != hipSuccess) return e;
+    }
     // Workgroup size: the one that keeps the most waves on a CU (the waves of a group share one copy of
     // the scene, so small scenes do best with 256-thread groups and large ones with 1024); ties go to
     // the smaller group.  RTIOW_DEBUG_THREADS pins it (tuning only).
@@ -3798,25 +3832,32 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     const uint32_t t_max = accel ? (shade_lds ? static_cast<uint32_t>(RTIOW_SMALL_MAX_THREADS) : static_cast<uint32_t>(kAccelMaxThreads)) : 1024u;
     uint32_t keep_env = kPassKeep;
     if (const char* v = debug_knob("RTIOW_DEBUG_PASS_KEEP")) keep_env = strtoul(v, nullptr, 10) ? kPassKeep : 0u;  // tuning only
-    for (int pass = 0; pass < 2; ++pass) {  // with the records first; without them only if that keeps more waves on a CU
-        const uint32_t keep = accel && pass == 0 ? keep_env : 0u;
-        if (pass == 1 && (!accel || keep_env == 0u)) break;  // (nothing new to try)
-        for (uint32_t t = 256u; t <= t_max; t += 256u) {
-            if (pinned != 0u && t != pinned) continue;
-            const size_t need = lds_scene + kGroupLdsBytes + static_cast<size_t>(t / 64u) * wave_bytes(keep);
-            if (need > kLdsPerCu) continue;
-            int blocks = 0;
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel_fn, static_cast<int>(t), need);
-            if (e != hipSuccess) return e;
-            if (blocks * static_cast<int>(t) > per_cu * static_cast<int>(threads)) {
-                threads = t;
-                per_cu = blocks;
-                lds = need;
-                g.pass_keep = keep;
-                g.wave_bytes = wave_bytes(keep);
+    void (*chosen_fn)(PathArgs, PersistArgs) = kernel_fn;
+    for (int variant = 0; variant < (compact_fn != nullptr ? 2 : 1); ++variant) {  // the compact per-wave area only if it keeps more waves on a CU
+        const bool compact = variant == 1;
+        void (*fn)(PathArgs, PersistArgs) = compact ? compact_fn : kernel_fn;
+        for (int pass = 0; pass < 2; ++pass) {  // with the records first; without them only if that keeps more waves on a CU
+            const uint32_t keep = accel && pass == 0 ? keep_env : 0u;
+            if (pass == 1 && (!accel || keep_env == 0u)) break;  // (nothing new to try)
+            for (uint32_t t = 256u; t <= (compact ? 1024u : t_max); t += 256u) {
+                if (pinned != 0u && t != pinned) continue;
+                const size_t need = lds_scene + kGroupLdsBytes + static_cast<size_t>(t / 64u) * wave_bytes_of(keep, compact);
+                if (need > kLdsPerCu) continue;
+                int blocks = 0;
+                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, static_cast<int>(t), need);
+                if (e != hipSuccess) return e;
+                if (blocks * static_cast<int>(t) > per_cu * static_cast<int>(threads)) {
+                    threads = t;
+                    per_cu = blocks;
+                    lds = need;
+                    g.pass_keep = keep;
+                    g.wave_bytes = wave_bytes_of(keep, compact);
+                    chosen_fn = fn;
+                }
             }
         }
     }
+    kernel_fn = chosen_fn;
     // camera paths a pass may make: one per lane, and no more than the records hold (those beyond pass_keep lie in the
     // work-list area: 42 of them, or all 64 in the two-level one)
     g.pass_min_idle = kPassMinLanes > g.pass_keep ? kPassMinLanes - g.pass_keep : 1u;
