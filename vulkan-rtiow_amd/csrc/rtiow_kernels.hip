@@ -1625,6 +1625,20 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
             }
         }
     }
+#ifndef RTIOW_CLAMP_TO_LARGE_HIT
+#define RTIOW_CLAMP_TO_LARGE_HIT 1  // (-DRTIOW_CLAMP_TO_LARGE_HIT=0: A/B only)
+#endif
+    if constexpr (FLAT && RTIOW_CLAMP_TO_LARGE_HIT != 0) {
+        // Round 5: a ray that has hit a large sphere at t_L -- the ground, for every ray that points down -- needs no box beyond t_L: a
+        // member that is hit closer (or as close: the tie goes by index) has its computed hit point inside its box -- that is what the
+        // boxes are inflated for (rtiow_clusters.cpp) -- so the ray enters that box no later than t_L.  The ray's far end in the common
+        // slab of a flat scene is one value per ray (FlatRay::tf_f): clamping it costs nothing per box.
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float t_large = key[r] != ~0ull ? __uint_as_float(static_cast<uint32_t>(key[r] >> 32)) * 1.000001f : __builtin_inff();
+            ay[r] = __builtin_fminf(ay[r], t_large);
+        }
+    }
     if (!SUPER || a.n_super == 0u) {
         // ---- phases 1 and 2, 32 clusters at a time ----
         for (uint32_t g0 = 0; g0 < a.n_clusters; g0 += 32u) {
@@ -2291,7 +2305,12 @@ DI void compact_to_slot0(Slot (&sl)[R], uint32_t* scratch) {
 constexpr uint32_t kPassSpans = 2;  // spans of consecutive pixels (of one row) a pass hands out at most: one per half of the wave
 constexpr uint32_t kPassRecBytes = 48;  // one waiting camera path: origin, direction, attenuation, RNG, entry | line | depth
 #ifndef RTIOW_PASS_KEEP
-#define RTIOW_PASS_KEEP 32  // records a wave keeps beyond its idle slots: a pass then runs on min(64, idle + 32) lanes
+#define RTIOW_PASS_KEEP 64  // records a wave keeps beyond its idle slots AT MOST (launch_path takes what the LDS has room for): a pass then
+                           // runs on min(64, idle + records) lanes.  (Rounds 2-4: 32, which is what two 512-thread groups per CU, each
+                           // with its own copy of the scene, left room for; the cover frame's passes then made 55 rays on average.
+                           // Round 5: ONE group of 1024 threads around one copy -- 26 KB of LDS back -- and 64 records: every pass on
+                           // all 64 lanes, 1.75 -> 1.5 million passes a frame; 32 / 36 / 40 records in two groups 5.71 / 5.69 / 5.63 ms,
+                           // 48 / 64 in one group 5.56 / 5.52: profiles/r05_ab_log.txt.)
 #endif
 #ifndef RTIOW_PASS_MIN_LANES
 #define RTIOW_PASS_MIN_LANES 32
@@ -2303,7 +2322,7 @@ constexpr uint32_t kPassKeep = RTIOW_PASS_KEEP;
 constexpr uint32_t kPassMinSpp = RTIOW_PASS_MIN_SPP;  // samples per pixel from which on camera rays take the pass (64 rays: <= 8 pixels;
                                                       // cover frame, pass off / on: 2 spp 0.84 / 1.20 ms, 4 spp 0.83 / 0.82, 8 spp 1.24 / 1.18)
 constexpr uint32_t kPassMinLanes = RTIOW_PASS_MIN_LANES;  // camera rays a pass must be able to make (idle slots + records) to be run
-static_assert(kPassKeep <= 32u && (64u - kPassKeep) * kPassRecBytes <= wave_item_bytes(false),
+static_assert(kPassKeep <= 64u && (64u - kPassKeep) * kPassRecBytes <= wave_item_bytes(false),
               "with pass_keep records of its own a wave's other records must fit the work-list area");
 
 struct ConeAxis {  // per lane: the cone of the span this half of the wave looks at
@@ -2516,8 +2535,9 @@ DI void primary_trace(const float4* slots, const uint32_t* idx_map, const float4
 }
 
 #ifndef RTIOW_SMALL_MAX_THREADS
-// largest group of the small-scene clustered variants: two groups of 512 per CU are their sixteen waves (below)
-#define RTIOW_SMALL_MAX_THREADS 512
+// largest group of the small-scene clustered variants: ONE group of 1024 threads per CU is their sixteen waves since round 5 (one copy of
+// the scene in LDS instead of two: room for 64 pass records per wave, see RTIOW_PASS_KEEP; rounds 3-4: two groups of 512)
+#define RTIOW_SMALL_MAX_THREADS 1024
 #endif
 #ifndef RTIOW_SMALL_WAVES_PER_EU
 #define RTIOW_SMALL_WAVES_PER_EU 1  // (this compilation: no constraint.  The Makefile's second pass over this file, which makes the
@@ -3836,9 +3856,8 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     for (int variant = 0; variant < (compact_fn != nullptr ? 2 : 1); ++variant) {  // the compact per-wave area only if it keeps more waves on a CU
         const bool compact = variant == 1;
         void (*fn)(PathArgs, PersistArgs) = compact ? compact_fn : kernel_fn;
-        for (int pass = 0; pass < 2; ++pass) {  // with the records first; without them only if that keeps more waves on a CU
-            const uint32_t keep = accel && pass == 0 ? keep_env : 0u;
-            if (pass == 1 && (!accel || keep_env == 0u)) break;  // (nothing new to try)
+        // as many pass records as the LDS has room for without losing a wave: most first, so that a tie in waves keeps the most records
+        for (uint32_t keep = accel ? keep_env : 0u;; keep = keep >= 8u ? keep - 8u : 0u) {
             for (uint32_t t = 256u; t <= (compact ? 1024u : t_max); t += 256u) {
                 if (pinned != 0u && t != pinned) continue;
                 const size_t need = lds_scene + kGroupLdsBytes + static_cast<size_t>(t / 64u) * wave_bytes_of(keep, compact);
@@ -3855,6 +3874,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
                     chosen_fn = fn;
                 }
             }
+            if (keep == 0u) break;
         }
     }
     kernel_fn = chosen_fn;
