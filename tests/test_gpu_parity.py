@@ -685,3 +685,41 @@ def test_round4_boundary_additions(gpu_ctx, rt):
     with pytest.raises(rt.RtError) as e:
         gpu_ctx.render(flat, V.make_params(64, 48, spp=1, max_depth=1, seed=1))
     assert e.value.code == V.RT_ERR_INVALID
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_cameras_at_the_edges_of_the_accepted_range_equal_the_oracle(gpu_ctx, oracle, kernel):
+    """rtRender's precondition on the camera (rtCameraIsRenderable: every ray from the lens to the image plane between 2^-30 and 2^40
+    long) is what lets the kernels normalise a camera ray by their six-instruction square root and three-instruction reciprocal; the only
+    GPU evidence for those was the scan of one float at a time (rtSelfTestUnaryScan).  Here whole frames are rendered by cameras that sit
+    AT the accepted edges -- the image plane as close to and as far from the lens as the check lets through, found by bisection -- and by
+    one whose lens is four times its focus distance, and compared with the oracle bit for bit."""
+    w, h = 64, 40
+
+    def cam_of(focus, aperture=0.0, frm=(0.0, 0.0, 0.0)):  # (at the origin: the float error of a ray is a few ulps of its LONGEST term)
+        return V.make_camera(frm, (0.0, 0.0, -1.0), (0, 1, 0), 40.0, w / h, aperture, focus)
+
+    def edge(lo, hi, ok_at_lo):  # the focus distance nearest the refused side that is still accepted (bisection over the exponent)
+        for _ in range(40):
+            mid = (lo * hi) ** 0.5
+            if V.camera_is_renderable(cam_of(mid)) == ok_at_lo:
+                lo = mid
+            else:
+                hi = mid
+        return lo if ok_at_lo else hi
+    nearest = edge(2.0 ** -33, 1.0, False)      # refused at 2^-33, accepted at 1
+    farthest = edge(1.0, 2.0 ** 42, True)       # accepted at 1, refused at 2^42
+    assert 2.0 ** -30.5 < nearest < 2.0 ** -29 and 2.0 ** 37 < farthest < 2.0 ** 40.5, (nearest, farthest)  # (farthest: the frame's corner ray, with u, v up to 2, is the 2^40 one)
+    assert not V.camera_is_renderable(cam_of(nearest * 0.98)) and not V.camera_is_renderable(cam_of(farthest * 1.02))
+    sph, mat = V.make_three_sphere_scene(True)
+    gpu_ctx.set_scene(sph, mat)
+    cases = [cam_of(nearest), cam_of(nearest * 1.37), cam_of(farthest), cam_of(farthest * 0.61), cam_of(1.0, aperture=4.0),
+             cam_of(2.0 ** -20, aperture=2.0 ** -19)]
+    for cam in cases:
+        assert V.camera_is_renderable(cam)
+        prm = V.make_params(w, h, spp=8, max_depth=50, seed=5, kernel=kernel)
+        want, segs = oracle.render(sph, mat, cam, prm)
+        got = gpu_ctx.render(cam, prm)
+        assert np.array_equal(got, want), _diff(got, want)
+        assert gpu_ctx.stats().segments == segs
+        assert len(np.unique(want[..., :3].reshape(-1, 3), axis=0)) > 50   # (a picture, not a constant)
