@@ -3853,29 +3853,61 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     uint32_t keep_env = kPassKeep;
     if (const char* v = debug_knob("RTIOW_DEBUG_PASS_KEEP")) keep_env = strtoul(v, nullptr, 10) ? kPassKeep : 0u;  // tuning only
     void (*chosen_fn)(PathArgs, PersistArgs) = kernel_fn;
-    for (int variant = 0; variant < (compact_fn != nullptr ? 2 : 1); ++variant) {  // the compact per-wave area only if it keeps more waves on a CU
-        const bool compact = variant == 1;
-        void (*fn)(PathArgs, PersistArgs) = compact ? compact_fn : kernel_fn;
-        // as many pass records as the LDS has room for without losing a wave: most first, so that a tie in waves keeps the most records
-        for (uint32_t keep = accel ? keep_env : 0u;; keep = keep >= 8u ? keep - 8u : 0u) {
-            for (uint32_t t = 256u; t <= (compact ? 1024u : t_max); t += 256u) {
-                if (pinned != 0u && t != pinned) continue;
-                const size_t need = lds_scene + kGroupLdsBytes + static_cast<size_t>(t / 64u) * wave_bytes_of(keep, compact);
-                if (need > kLdsPerCu) continue;
-                int blocks = 0;
-                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, static_cast<int>(t), need);
-                if (e != hipSuccess) return e;
-                if (blocks * static_cast<int>(t) > per_cu * static_cast<int>(threads)) {
-                    threads = t;
-                    per_cu = blocks;
-                    lds = need;
-                    g.pass_keep = keep;
-                    g.wave_bytes = wave_bytes_of(keep, compact);
-                    chosen_fn = fn;
+    // (The search below asks the occupancy API up to 72 times: its result is remembered per thread for the last few (kernel, scene size)
+    // pairs -- a frame loop launches the same configuration every frame, and rtRender's host cost is part of a small frame's rate.)
+    struct LaunchChoice {
+        const void *fn = nullptr, *compact = nullptr;
+        size_t lds_scene = 0;
+        uint32_t item_bytes = 0, keep_env = 0, pinned = 0, t_max = 0;
+        uint32_t threads = 0, pass_keep = 0, wave_bytes = 0;
+        int per_cu = 0;
+        size_t lds = 0;
+        const void* chosen = nullptr;
+    };
+    static thread_local LaunchChoice cache[4];
+    static thread_local uint32_t cache_next = 0u;
+    const LaunchChoice* hit = nullptr;
+    for (const LaunchChoice& c : cache)
+        if (c.fn == reinterpret_cast<const void*>(kernel_fn) && c.compact == reinterpret_cast<const void*>(compact_fn) && c.lds_scene == lds_scene &&
+            c.item_bytes == item_bytes && c.keep_env == keep_env && c.pinned == pinned && c.t_max == t_max)
+            hit = &c;
+    if (hit != nullptr) {
+        threads = hit->threads;
+        per_cu = hit->per_cu;
+        lds = hit->lds;
+        g.pass_keep = hit->pass_keep;
+        g.wave_bytes = hit->wave_bytes;
+        chosen_fn = reinterpret_cast<void (*)(PathArgs, PersistArgs)>(const_cast<void*>(hit->chosen));
+    } else {
+        for (int variant = 0; variant < (compact_fn != nullptr ? 2 : 1); ++variant) {  // the compact per-wave area only if it keeps more waves on a CU
+            const bool compact = variant == 1;
+            void (*fn)(PathArgs, PersistArgs) = compact ? compact_fn : kernel_fn;
+            // as many pass records as the LDS has room for without losing a wave: most first, so that a tie in waves keeps the most records
+            for (uint32_t keep = accel ? keep_env : 0u;; keep = keep >= 8u ? keep - 8u : 0u) {
+                for (uint32_t t = 256u; t <= (compact ? 1024u : t_max); t += 256u) {
+                    if (pinned != 0u && t != pinned) continue;
+                    const size_t need = lds_scene + kGroupLdsBytes + static_cast<size_t>(t / 64u) * wave_bytes_of(keep, compact);
+                    if (need > kLdsPerCu) continue;
+                    int blocks = 0;
+                    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, static_cast<int>(t), need);
+                    if (e != hipSuccess) return e;
+                    if (blocks * static_cast<int>(t) > per_cu * static_cast<int>(threads)) {
+                        threads = t;
+                        per_cu = blocks;
+                        lds = need;
+                        g.pass_keep = keep;
+                        g.wave_bytes = wave_bytes_of(keep, compact);
+                        chosen_fn = fn;
+                    }
                 }
+                if (keep == 0u) break;
             }
-            if (keep == 0u) break;
         }
+        LaunchChoice& c = cache[cache_next++ % 4u];
+        c.fn = reinterpret_cast<const void*>(kernel_fn); c.compact = reinterpret_cast<const void*>(compact_fn); c.lds_scene = lds_scene;
+        c.item_bytes = item_bytes; c.keep_env = keep_env; c.pinned = pinned; c.t_max = t_max;
+        c.threads = threads; c.per_cu = per_cu; c.lds = lds; c.pass_keep = g.pass_keep; c.wave_bytes = g.wave_bytes;
+        c.chosen = reinterpret_cast<const void*>(chosen_fn);
     }
     kernel_fn = chosen_fn;
     // camera paths a pass may make: one per lane, and no more than the records hold (those beyond pass_keep lie in the
