@@ -4,6 +4,7 @@
 #   small: path_persistent_kernel<true,true,true>   (C3's default kernel; its own compilation pass, SMALL_FLAGS)
 #   large: path_persistent_kernel<false,true,true>  (C5's)
 #   flat : path_persistent_kernel<true,false,false> (C2's; the whole-file pass)
+#   compact: path_persistent_kernel<false,true,true,true> (C5's since round 5: four waves per SIMD; the whole-file pass)
 set -e
 WHICH=${1:-small}
 R=$(cd "$(dirname "$0")/../.." && pwd)
@@ -17,6 +18,7 @@ case $WHICH in
   small) PASS="-DRTIOW_TU_SMALL_CLUSTERED -DRTIOW_SMALL_WAVES_PER_EU=4 -Wno-unused-function -Wno-unused-const-variable"; OBJ=rtiow_kernels_small; KEY=${2:-path_persistent_kernelILb1ELb1ELb1E};;
   large) PASS="-DRTIOW_TU_LARGE_CLUSTERED -mllvm -amdgpu-sched-strategy=iterative-ilp -Wno-unused-function -Wno-unused-const-variable"; OBJ=rtiow_kernels_large; KEY=${2:-path_persistent_kernelILb0ELb1ELb1E};;
   flat)  PASS=""; OBJ=rtiow_kernels; KEY=${2:-path_persistent_kernelILb1ELb0ELb0E};;
+  compact) PASS=""; OBJ=rtiow_kernels; KEY=${2:-path_persistent_kernelILb0ELb1ELb1ELb1E};;
 esac
 # 1. the whole library with the extended counter block (host side: allocation, zeroing, dump)
 make -s -C $C OUT=../librtiow_hip_blk.so EXTRA="-DRTIOW_DEBUG_KNOBS -DRTIOW_BLOCK_COUNTERS=$N" -j8 > $B/make.log 2>&1 || { tail -20 $B/make.log; exit 1; }

@@ -30,6 +30,15 @@ nfv_i = next(i for i in range(desc, len(lines)) if ".amdhsa_next_free_vgpr" in l
 nfv = int(lines[nfv_i].split()[-1])
 acc_i = next(i for i in range(desc, len(lines)) if ".amdhsa_accum_offset" in lines[i])
 vS, vB = nfv, nfv + 1
+# the two spare registers must not cost a launch its largest workgroup: a 1024-thread group is four waves per SIMD, 512 registers between them
+meta = "\n".join(lines)
+mwg = re.search(r"\.max_flat_workgroup_size:\s*(\d+)\s*\n\s*\.name:\s*" + re.escape(name), meta)
+if mwg:
+    waves_per_simd = (int(mwg.group(1)) + 255) // 256
+    alloc = (nfv + 2 + 7) // 8 * 8
+    if waves_per_simd * alloc > 512:
+        sys.exit(f"blockprof: {name} may run {mwg.group(1)}-thread groups ({waves_per_simd} waves per SIMD) and uses {nfv} VGPRs: two more would not fit "
+                 f"512 registers per SIMD lane -- the launch would be refused (HSA_STATUS_ERROR_INVALID_ISA).  Not instrumented.")
 lines[nfv_i] = f"\t\t.amdhsa_next_free_vgpr {nfv + 2}"
 lines[acc_i] = f"\t\t.amdhsa_accum_offset {(nfv + 2 + 3) // 4 * 4}"
 
