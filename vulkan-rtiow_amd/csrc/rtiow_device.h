@@ -154,16 +154,18 @@ struct ChArgs {
     uint32_t row_blocks, row_block_stride;  // (set by launch_ch) two-phase kernel: grid row g renders row block g * stride mod row_blocks
 };
 
-// Chunks of the persistent kernels' pixel queue.  One chunk = 32 pixels = one 128-byte line of the frame: all its
-// stores come from the XCD whose queue holds it.  Also the unit of the cost order: measured on the cover frame, one
-// eighth of it (tools/ab_bench.py): 256 pixels 1.71 ms, 128: 1.67, 64: 1.69, 32: 1.64 (32 without the order: 1.72);
-// whole frame 10.31-10.40 either way.
+// Chunks of the persistent kernels' pixel queue.  One chunk = 16 pixels = half a 128-byte line of the frame: all its
+// stores come from the XCD whose queue holds it.  Also the unit of the cost order.  Rounds 2-4: 32 pixels (one eighth of the
+// cover frame, tools/ab_bench.py: 256 pixels 1.71 ms, 128: 1.67, 64: 1.69, 32: 1.64).  Round 5: what ends a small frame is dear pixels
+// that sit in chunks of middling cost and are therefore STARTED late (tools/wavelog.py), and a finer order starts them earlier: 16
+// pixels take one eighth of the cover frame from 0.883 to 0.864 ms and a quarter from 1.61 to 1.57; the whole frame, a 16-spp frame and
+// C5 (whole-chunk line stores of 64 bytes instead of 128) stay where they were; 8 pixels lose 5 % (profiles/r05_ab_log.txt).
 #ifndef RTIOW_CHUNK_PIX
-#define RTIOW_CHUNK_PIX 32
+#define RTIOW_CHUNK_PIX 16
 #endif
 constexpr uint32_t kChunkPixels = RTIOW_CHUNK_PIX;
 // LDS a wave of the persistent kernels has to itself (rtiow_kernels.hip: path_persistent_kernel lays it out, launch_path sizes it)
-constexpr uint32_t kChunkPix = kChunkPixels;         // pixels per XCD-queue chunk: 32 = one 128-byte line of the frame
+constexpr uint32_t kChunkPix = kChunkPixels;         // pixels per XCD-queue chunk
 constexpr uint32_t kLineBufs = 4;                    // whole chunks a wave may be assembling: 32 RGBA8 pixels each +
 constexpr uint32_t kLineMetaWords = 4;               // ... {pixels done, pixels expected, segments they took (u64)}
 constexpr uint32_t kWaveLineBytes = kLineBufs * (kChunkPix + kLineMetaWords) * 4u;
