@@ -3965,10 +3965,12 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     g.chunk_pool = g.pool_pix / kChunkPix * kChunkPix;
     if (g.chunk_pool < kChunkPix) g.chunk_pool = kChunkPix;
     g.chunk_until = (g.total_waves / 8u + 1u) * 24u + g.chunk_pool;
-    // ... and only for frames with at least 256 pixels per wave: a chunk is 32 pixels of ONE wave's time, the dearest
+    // ... and only for frames with at least 256 pixels per wave: a chunk is a run of pixels of ONE wave's time, the dearest
     // of them (glass, ten times the average) ten chunks' worth; on one eighth of the cover frame (39 pixels per wave) whole
-    // chunks made the tile take 3.9 ms instead of 1.7
-    if (g.total_pix / kChunkPix < g.total_waves * 8u) g.chunk_until = ~0u;
+    // chunks made the tile take 3.9 ms instead of 1.7.  (256 pixels whatever the chunk: with the 16-pixel chunks of round 5 and the rule
+    // left at "eight chunks" the cover frame -- 234 pixels per wave -- took whole chunks, and an orbiting camera, whose order is the last
+    // view's, paid 17.7 % over its own views standing still instead of 3.6 %.)
+    if (g.total_pix / 256u < g.total_waves) g.chunk_until = ~0u;
     // ... and only in the order of the last frame's costs, where the queue ends on the cheapest chunks.  In natural order
     // a dear chunk may come last and its wave finish alone: the first frame of a shape took 10.9-11.1 ms with whole
     // chunks against 10.5 without (9.6 once the order is there).
