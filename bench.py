@@ -487,9 +487,11 @@ def run(args, np, torch, dist, V, D, world, rank, local_rank, backend, dev):
         if world == 1:  # PMC traffic of this workload + kernel, newest profile first
             for tpath in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
                 tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload and tj.get("bench_kernel") == KERNEL_NAMES.get(eff_kernel):
-                    if tj.get("kernel_source_sha16") == kernel_source_sha16():  # (of these kernels, not of an earlier round's)
-                        traffic = tj.get("hbm_bytes_per_launch")
+                # (of this workload and kernel AND of these kernel sources: a profile of an earlier round's kernels, or of the A/B baseline
+                # a round began with, is passed over)
+                if (tj.get("workload") == args.workload and tj.get("bench_kernel") == KERNEL_NAMES.get(eff_kernel)
+                        and tj.get("kernel_source_sha16") == kernel_source_sha16()):
+                    traffic = tj.get("hbm_bytes_per_launch")
                     break
         # VALU issue utilisation of the same kernel from the committed PMC profile (SQ_INSTS_VALU per launch)
         # against the issue rate tools/ubench_valu.hip measures for back-to-back v_fma_f32 on this part
