@@ -531,3 +531,29 @@ def test_camera_precondition_accepts_every_sane_camera_and_refuses_the_rest():
     bad.append(V.make_camera((1e6, 2.0, 3.0), (1e6 + 0.5, 0, 0), (0, 1, 0), 30.0, 1.5, 0.0, 0.5))  # ... half a unit: the float ray is noise
     for cam in bad + [flat, nan]:
         assert not V.camera_is_renderable(cam)
+
+
+def test_blockprof_instruments_the_default_kernel_and_refuses_one_without_spare_registers():
+    """tools/blockprof (round 5): one scalar atomic in front of every basic block of a kernel's assembly.  On the CPU: the default kernel's
+    assembly is instrumented, assembles and links into librtiow_hip_blk.so (hipcc cross-compiles), every block got its counter, and the
+    tool refuses the COMPACT large-scene variant -- 128 registers in 1024-thread groups: two more would make the launch fail."""
+    import json
+    import shutil
+    import subprocess
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    build = os.path.join(ROOT, "tools", "blockprof", "build.sh")
+    res = subprocess.run(["bash", build, "compact"], capture_output=True, text=True, timeout=900)
+    assert res.returncode != 0 and "Not instrumented" in (res.stdout + res.stderr)
+    res = subprocess.run(["bash", build, "small"], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    m = json.load(open(os.path.join(ROOT, "tools", "blockprof", "_build", "small_map.json")))
+    assert "path_persistent_kernelILb1ELb1ELb1E" in m["kernel"] and len(m["blocks"]) > 500
+    asm = open(os.path.join(ROOT, "tools", "blockprof", "_build", "rtiow_kernels_small_blk.s")).read()
+    body = asm[asm.index(m["kernel"] + ":"):]
+    body = body[:body.index(".amdhsa_kernel " + m["kernel"])]
+    assert body.count("s_atomic_add s2, s[0:1]") == len(m["blocks"])          # one counter per block ...
+    offsets = sorted(int(x, 16) for x in re.findall(r"s_atomic_add s2, s\[0:1\], 0x([0-9a-f]+)", body))
+    assert offsets == [128 * b for b in range(len(m["blocks"]))]               # ... each on a 128-byte line of its own
+    assert sum(len(b) for b in m["blocks"]) > 8000                             # the static instruction lists report.py multiplies them with
+    assert os.path.exists(os.path.join(ROOT, "vulkan-rtiow_amd", "librtiow_hip_blk.so"))
