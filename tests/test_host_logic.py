@@ -557,3 +557,19 @@ def test_blockprof_instruments_the_default_kernel_and_refuses_one_without_spare_
     assert offsets == [128 * b for b in range(len(m["blocks"]))]               # ... each on a 128-byte line of its own
     assert sum(len(b) for b in m["blocks"]) > 8000                             # the static instruction lists report.py multiplies them with
     assert os.path.exists(os.path.join(ROOT, "vulkan-rtiow_amd", "librtiow_hip_blk.so"))
+    # `lanes`: the same plus the active lanes of every stretch that runs under one EXEC -- a stretch ends at every write of EXEC too, SCC is
+    # kept around the population count, and the branches the tripled code pushes out of reach go over trampolines (relax.py assembles)
+    bdir = os.path.join(ROOT, "tools", "blockprof", "_build")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "blockprof", "instrument.py"), os.path.join(bdir, "rtiow_kernels_small.s"),
+                          os.path.join(bdir, "lanes_test.s"), os.path.join(bdir, "lanes_test_map.json"), "path_persistent_kernelILb1ELb1ELb1E", "280", "3584",
+                          "lanes"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    ml = json.load(open(os.path.join(bdir, "lanes_test_map.json")))
+    assert ml["lanes"] and len(ml["blocks"]) > len(m["blocks"])
+    for blk in ml["blocks"]:  # EXEC is written by a stretch's last instruction only
+        assert not any(rest.split(",")[0].strip() in ("exec", "exec_lo", "exec_hi") or "saveexec" in op or op.startswith("v_cmpx") for op, rest, _ in blk[:-1])
+    asm = open(os.path.join(bdir, "lanes_test.s")).read()
+    assert asm.count("s_bcnt1_i32_b64 s4, exec") == len(ml["blocks"]) == asm.count("s_cselect_b32 s3, 1, 0") == asm.count("s_cmp_lg_u32 s3, 0\n\tv_readlane_b32 s0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "blockprof", "relax.py"), os.path.join(bdir, "lanes_test.s"), os.path.join(bdir, "lanes_test.o")],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "trampolines" in res.stdout, res.stdout[-500:] + res.stderr[-2000:]

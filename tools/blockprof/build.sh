@@ -1,6 +1,7 @@
 #!/bin/bash
 # Builds vulkan-rtiow_amd/librtiow_hip_blk.so: the library with basic-block execution counters in ONE family of the persistent
-# kernels (tools/blockprof/instrument.py).  usage: build.sh small|large|flat [kernel-name-substring]
+# kernels (tools/blockprof/instrument.py).  usage: [BLOCKPROF_LANES=1] build.sh small|large|flat [kernel-name-substring]
+#   BLOCKPROF_LANES=1: the counters also sum the active lanes (blocks cut at every write of EXEC): lane occupancy by region
 #   small: path_persistent_kernel<true,true,true>   (C3's default kernel; its own compilation pass, SMALL_FLAGS)
 #   large: path_persistent_kernel<false,true,true>  (C5's)
 #   flat : path_persistent_kernel<true,false,false> (C2's; the whole-file pass)
@@ -33,9 +34,9 @@ EOC
 read OFF_COUNTERS OFF_BLOCKS SIZE < <($B/offsets)
 # 3. the device assembly of that pass (with line tables: report.py attributes instructions to source lines), instrumented
 /opt/rocm/bin/hipcc $FLAGS $PASS -gline-tables-only --cuda-device-only -S -o $B/$OBJ.s $C/rtiow_kernels.hip
-python3 $R/tools/blockprof/instrument.py $B/$OBJ.s $B/${OBJ}_blk.s $B/${WHICH}_map.json $KEY $OFF_COUNTERS $OFF_BLOCKS
+python3 $R/tools/blockprof/instrument.py $B/$OBJ.s $B/${OBJ}_blk.s $B/${WHICH}_map.json $KEY $OFF_COUNTERS $OFF_BLOCKS ${BLOCKPROF_LANES:+lanes}
 # 4. assemble -> code object -> fat binary -> the host half of the same translation unit around it
-$LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $B/${OBJ}_blk.s -o $B/${OBJ}_blk.dev.o
+python3 $R/tools/blockprof/relax.py $B/${OBJ}_blk.s $B/${OBJ}_blk.dev.o   # (assembles; trampolines for branches the counters pushed out of reach)
 $LLVM/lld -flavor gnu -m elf64_amdgpu --no-undefined -shared -o $B/${OBJ}_blk.hsaco $B/${OBJ}_blk.dev.o
 $LLVM/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950 \
     -input=/dev/null -input=$B/${OBJ}_blk.hsaco -output=$B/${OBJ}_blk.hipfb

@@ -14,11 +14,17 @@ Inserted per block (wave-uniform, EXEC-independent, SCC / VCC / EXEC / M0 untouc
     v_readlane_b32  s0..s2 <- vS ; s_nop 4        restore (the nops: a VALU-written SGPR must age before VMEM / lane-select reads it)
 vS, vB are the two vector registers after the kernel's own (.amdhsa_next_free_vgpr is raised by two).
 
-usage: instrument.py in.s out.s map.json <kernel-name-substring> <kernarg offset of PathArgs::counters> <offset of Counters::block_counts>
+With a seventh argument `lanes` every counter also sums the ACTIVE LANES at its block's entry (s_bcnt1_i32_b64 of EXEC into a 64-bit sum eight
+bytes after the entry count; SCC is saved around it), and a block is also cut after every instruction that writes EXEC, so that every counted
+stretch of instructions runs under one EXEC: report.py then gives the lane occupancy of the vector instructions region by region, which must
+reproduce SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU) of the un-instrumented kernel.
+
+usage: instrument.py in.s out.s map.json <kernel-name-substring> <kernarg offset of PathArgs::counters> <offset of Counters::block_counts> [lanes]
 """
 import json, re, sys
 
 src, dst, map_path, key, off_counters, off_blocks = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5], 0), int(sys.argv[6], 0)
+LANES = len(sys.argv) > 7 and sys.argv[7] == "lanes"
 STRIDE = 128  # bytes between counters: one 128-byte line each, so that hot blocks do not queue behind each other in one L2 channel
 lines = open(src).read().split("\n")
 start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l) and key in l)
@@ -47,7 +53,25 @@ BRANCH = re.compile(r"^(s_cbranch_\w+|s_branch|s_setpc_b64|s_swappc_b64|s_endpgm
 LABEL = re.compile(r"^(\.LBB\d+_\d+|_Z\w+):")
 
 
+def writes_exec(op, rest):
+    dest = rest.split(",")[0].strip()
+    return dest in ("exec", "exec_lo", "exec_hi") or "saveexec" in op or op.startswith("v_cmpx")
+
+
+def counter_code_lanes(b):
+    # s3: SCC while s_bcnt1 overwrites it; s[4:5]: the lanes of EXEC as a 64-bit addend
+    sv = [f"\tv_writelane_b32 v{vS}, s{k}, {k}" for k in range(6)]
+    rs = [f"\tv_readlane_b32 s{k}, v{vS}, {k}" for k in range(6)]
+    return [f"\t; ---- blockprof: block {b}", "\ts_waitcnt lgkmcnt(0)"] + sv + [
+            "\ts_cselect_b32 s3, 1, 0", f"\tv_readlane_b32 s0, v{vB}, 0", f"\tv_readlane_b32 s1, v{vB}, 1", "\ts_mov_b32 s2, 1", "\ts_mov_b32 s5, 0",
+            "\ts_nop 4", "\ts_bcnt1_i32_b64 s4, exec",
+            f"\ts_atomic_add s2, s[0:1], 0x{b * STRIDE:x}", f"\ts_atomic_add_x2 s[4:5], s[0:1], 0x{b * STRIDE + 8:x}", "\ts_waitcnt lgkmcnt(0)",
+            "\ts_cmp_lg_u32 s3, 0"] + rs + ["\ts_nop 4"]
+
+
 def counter_code(b):
+    if LANES:
+        return counter_code_lanes(b)
     # (the first wait: a scalar load still in flight may have s0..s2 as its destination -- saved before it lands and restored after, they
     # would lose what it loaded)
     return [f"\t; ---- blockprof: block {b}", "\ts_waitcnt lgkmcnt(0)",
@@ -88,11 +112,11 @@ for l in lines[start + 1:end]:
         at_head = False
     blocks[-1].append([op, rest, cur_line])
     out.append(l)
-    if BRANCH.match(op):
+    if BRANCH.match(op) or (LANES and writes_exec(op, rest)):
         at_head = True
 out += lines[end:]
 open(dst, "w").write("\n".join(out))
 files = {int(mm.group(1)): mm.group(2) for mm in (re.match(r'\s+\.file\s+(\d+)\s+"[^"]*"\s+"([^"]*)"', l) for l in lines) if mm}
-json.dump({"files": files, "kernel": name, "stride_bytes": STRIDE, "blocks": blocks, "spare_vgprs": [vS, vB]}, open(map_path, "w"))
+json.dump({"files": files, "kernel": name, "stride_bytes": STRIDE, "blocks": blocks, "spare_vgprs": [vS, vB], "lanes": LANES}, open(map_path, "w"))
 n_ins = sum(len(b) for b in blocks)
-print(f"{name}: {len(blocks)} blocks, {n_ins} instructions, {len(blocks) * 14 + 8} inserted; spare registers v{vS}, v{vB}; counters need {len(blocks) * STRIDE} bytes")
+print(f"{name}: {len(blocks)} blocks, {n_ins} instructions, {len(blocks) * len(counter_code(0)) - len(blocks) + 8} inserted; spare registers v{vS}, v{vB}; counters need {len(blocks) * STRIDE} bytes")

@@ -9,7 +9,9 @@ root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 n_lines = int(sys.argv[sys.argv.index("--lines") + 1]) if "--lines" in sys.argv else 30
 m = json.load(open(args[0]))
-counts = [int(x) for x in open(args[1]).read().split()]
+rows_ = [l.split() for l in open(args[1]).read().split("\n") if l.strip()]
+counts = [int(r[0]) for r in rows_]
+lanes = [int(r[1]) for r in rows_] if m.get("lanes") and all(len(r) > 1 for r in rows_) else None  # active lanes summed over the entries
 blocks = m["blocks"]
 assert len(counts) >= len(blocks)
 
@@ -137,6 +139,13 @@ for b, ins in enumerate(blocks):
         by_kind[(cl, kind)] += c
         r = ctx_r[k_i]
         by_region[r][cl] += c
+        if lanes and cl == "valu" and kind != "readlane/writelane":  # (lane-select instructions run whatever EXEC is)
+            by_region[r]["valu_x"] += c
+            by_region[r]["lanes"] += lanes[b]
+            by_line[line]["valu_x"] += c
+            by_line[line]["lanes"] += lanes[b]
+            by_class["valu_x"] += c
+            by_class["lanes"] += lanes[b]
         if kind == "readlane/writelane":
             by_region[r]["rw"] += c
         by_line[line][cl] += c
@@ -172,20 +181,44 @@ for (cl, kind), c in sorted(by_kind.items(), key=lambda kv: -kv[1]):
     if pmc and kind in PMC_KIND and PMC_KIND[kind] in pmc:
         line += f"   [{PMC_KIND[kind]} {pmc[PMC_KIND[kind]]:.5g}, {c / max(1.0, pmc[PMC_KIND[kind]]):.4f}]"
     print(line)
+if lanes:
+    occ = by_class["lanes"] / (64.0 * max(1, by_class["valu_x"]))
+    line = f"\n    lane occupancy of the vector instructions (active lanes at the entry of each stretch under one EXEC / 64): {occ:.4f}"
+    print(line)
+    if pmc and "SQ_THREAD_CYCLES_VALU" in pmc:
+        # the counter takes a v_readlane / v_writelane / v_readfirstlane (no EXEC: one lane read or written) as ONE thread
+        n_rw = by_kind[("valu", "readlane/writelane")]
+        occ_hw = (by_class["lanes"] + n_rw) / (64.0 * (by_class["valu_x"] + n_rw))
+        ref = pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"])
+        print(f"    with the lane-select instructions as one lane each, as the SQ counters take them: {occ_hw:.4f}   [SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU) {ref:.4f}, ratio {occ_hw / ref:.4f}]")
 print("\n(2) by source region (rtiow_kernels.hip; inlined code counts under its own function)      valu    share   readlane/writelane     salu      lds")
 for r, c in sorted(by_region.items(), key=lambda kv: -kv[1]["valu"]):
     if c["valu"] + c["salu"] < 0.002 * tv:
         continue
-    print(f"    {r:52s} {c['valu']:12.4g}  {c['valu'] / tv:6.3f}   {c['rw']:12.4g}     {c['salu']:12.4g} {c['lds']:10.4g}")
+    extra = f"   lanes {c['lanes'] / (64.0 * c['valu_x']):5.3f}  idle lane-slots {(64.0 * c['valu_x'] - c['lanes']) / (64.0 * tv):6.4f} of all" if lanes and c["valu_x"] else ""
+    print(f"    {r:52s} {c['valu']:12.4g}  {c['valu'] / tv:6.3f}   {c['rw']:12.4g}     {c['salu']:12.4g} {c['lds']:10.4g}{extra}")
 print(f"\n(3) the {n_lines} hottest source lines (vector instructions executed)")
 src = open(srcfile).read().split("\n")
 for line, c in sorted(by_line.items(), key=lambda kv: -kv[1]["valu"])[:n_lines]:
     text = src[line - 1].strip()[:110] if 0 < line <= len(src) else ""
-    print(f"    {line:5d} {c['valu']:12.4g} {c['valu'] / tv:6.3f}  salu {c['salu']:10.4g}  | {region_of(line)[:24]:24s} | {text}")
+    extra = f" lanes {c['lanes'] / (64.0 * c['valu_x']):5.3f} |" if lanes and c["valu_x"] else ""
+    print(f"    {line:5d} {c['valu']:12.4g} {c['valu'] / tv:6.3f}  salu {c['salu']:10.4g}  |{extra} {region_of(line)[:24]:24s} | {text}")
 
 print("\n(4) v_readlane / v_writelane / v_readfirstlane by basic block: executed, block entries x instructions in it, block, its regions, its source lines")
 for tot, c, n_rw, b, regs, span in sorted(rw_blocks, reverse=True)[:40]:
     print(f"    {tot:12.4g} = {c:10d} x {n_rw:3d}   block {b:4d} ({len(blocks[b]):4d} instructions)  {', '.join(f'{r} ({k})' for r, k in regs):60s} lines {span}")
+
+if lanes:
+    print("\n(4b) idle lane-slots by stretch (vector instructions x (64 x entries - active lanes)): share of all lane-slots, occupancy, entries, vector instructions, block, regions, lines")
+    rows = []
+    for b, ins in enumerate(blocks):
+        n = sum(1 for op, rest, line in ins if classify(op, rest)[0] == "valu" and classify(op, rest)[1] != "readlane/writelane")
+        if n and counts[b]:
+            rows.append((n * (64 * counts[b] - lanes[b]), lanes[b] / (64.0 * counts[b]), counts[b], n, b))
+    for lost, occ_b, c, n, b in sorted(rows, reverse=True)[:40]:
+        regs = collections.Counter(context_regions(blocks[b])).most_common(2)
+        ls = sorted({l for _, _, l in blocks[b] if l > 0})
+        print(f"    {lost / (64.0 * tv):7.4f}  {occ_b:5.3f}  {c:10d} x {n:3d}   block {b:4d}  {', '.join(f'{r} ({k})' for r, k in regs):60s} lines {ls[:1] + ls[-1:]}")
 
 # --kind K: the blocks that execute most instructions of one kind (mov, cndmask, cmp, int/bit, salu ...); --block B: a block's listing
 if "--kind" in sys.argv:

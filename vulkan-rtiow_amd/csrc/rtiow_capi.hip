@@ -552,7 +552,11 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
 #ifdef RTIOW_BLOCK_COUNTERS
         if (const char* path = std::getenv("RTIOW_BLOCK_DUMP")) {  // (tools/blockprof builds only) one line per basic-block counter
             if (FILE* f = fopen(path, "w")) {
-                for (uint32_t b = 0; b < RTIOW_BLOCK_COUNTERS; ++b) fprintf(f, "%u\n", ctx->h_counters->block_counts[b * 32u]);
+                // (entries, and the active lanes summed over them where the kernel was instrumented with `lanes`: a 64-bit sum eight bytes on)
+                for (uint32_t b = 0; b < RTIOW_BLOCK_COUNTERS; ++b) {
+                    const uint32_t* c = ctx->h_counters->block_counts + b * 32u;
+                    fprintf(f, "%u %llu\n", c[0], static_cast<unsigned long long>(c[2]) | static_cast<unsigned long long>(c[3]) << 32);
+                }
                 fclose(f);
             }
         }
