@@ -20,7 +20,7 @@ with V.Context(0) as ctx:
         d[2] &= 0xFFFFFFFF
         iters = max(1, d[2])
         print(f"take {chunk}: {st.kernel_ms:.2f} ms segs {st.segments} wave-iters {d[2]} "
-              f"lane-slot utilisation {st.segments / (iters * 128):.3f} "
+              f"segments per iteration and slot {st.segments / (iters * 128):.3f} (all; the passes trace the camera segments: {(st.segments - st.paths) / (iters * 128):.3f} without -- kernel 3 at spp >= 8) "
               f"slow trips/iter {d[0] / iters:.2f} (per slot {d[0] / iters / 2:.2f}) "
               f"cands/segment {d[1] / max(1, st.segments):.2f} sparse iters {sparse} tests/segment {st.sphere_tests / max(1, st.segments):.1f}")
         tot = max(1, d[3] + d[4] + d[6])
