@@ -1900,6 +1900,15 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
     }
 }
 
+// A 64-bit constant (both words `word`) made where it is stored.  Left to itself the compiler makes the register pair in the kernel's first
+// block and keeps it to the last; the COMPACT variant, at its 128 registers, spilled two such pairs (0 for a fresh accumulator entry, ~0 for
+// fresh result keys) to scratch and read them back inside the loops: its only scratch traffic.  Two v_mov at the store instead.
+DI unsigned long long fresh64(uint32_t word) {
+    uint32_t lo = word, hi = word;
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
 DI uint32_t lane_rank(unsigned long long mask) {  // number of set bits of mask below this lane
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
@@ -1969,7 +1978,7 @@ DI void trace_sparse_parallel(const float4* slots, const uint32_t* idx_map, cons
             dst[2] = make_float2(p.du.y, p.du.z);
         }
     }
-    if (lane < n_live) keys[lane] = ~0ull;
+    if (lane < n_live) keys[lane] = fresh64(~0u);
     // (a wave's LDS operations are performed in order: rays and keys are in place for what follows)
     const bool two_level = SUPER && a.n_super != 0u;
     const uint32_t top = two_level ? a.n_clusters : 0u;  // number of the first box of the top level
@@ -2163,7 +2172,7 @@ DI void trace_sparse_batched(const float4* slots, const uint32_t* idx_map, const
         dst[1] = make_float2(p.o.z, p.du.x);
         dst[2] = make_float2(p.du.y, p.du.z);
     }
-    if (lane < n_live) keys[lane] = ~0ull;
+    if (lane < n_live) keys[lane] = fresh64(~0u);
     // (a wave's LDS operations are performed in order: rays and keys are in place for what follows)
     uint32_t shift = 6u;  // log2 of the lanes a path gets
     while ((n_live << shift) > 64u) --shift;
@@ -2683,7 +2692,12 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     uint32_t tl_deepest = 0u;            // (per lane) deepest path finished after dry
     unsigned long long tl_deep_end = 0ull;  // (per lane) when the last path of 40+ segments finished
 #endif
+    // Paths started, segments shaded, tests made: per lane -- or, paths and segments in the large-scene variants, per wave: scalars, where the
+    // per-lane counts of rounds 1-4 were two registers all kernel long (the COMPACT variant spilled one).  The small-scene variants have the
+    // registers and are short of scalars: the cover frame was 0.5 % slower with the scalar counts (profiles/r05_ab_log.txt).
+    constexpr bool kWaveCounts = ACCEL && !SHADE_LDS;
     uint32_t n_paths = 0, n_segments = 0, n_tests = 0;
+    uint32_t wave_paths = 0, wave_segments = 0;
 #ifdef RTIOW_DEBUG_WAVE_POOLS
     uint32_t dbg_pools_drawn = 0u;
 #endif
@@ -2708,10 +2722,12 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
 #ifndef RTIOW_SHADE_EARLY_OUT
 #define RTIOW_SHADE_EARLY_OUT 1  // (-DRTIOW_SHADE_EARLY_OUT=0: A/B only)
 #endif
-        if (RTIOW_SHADE_EARLY_OUT && __ballot(q.active) == 0ull) return;  // (sparse iterations keep their paths in slot 0)
+        const unsigned long long shaded = __ballot(q.active);
+        if (RTIOW_SHADE_EARLY_OUT && shaded == 0ull) return;  // (sparse iterations keep their paths in slot 0)
+        if constexpr (kWaveCounts) wave_segments += static_cast<uint32_t>(__popcll(shaded));
         bool finished = false;
         if (q.active) {
-            ++n_segments;
+            if constexpr (!kWaveCounts) ++n_segments;
             unsigned long long* acc = lds_acc + meta_entry(q.meta) * kAccWords;
             if (hit_slot < 0) {
                 const f3 rad = sky_radiance(q.p);
@@ -2754,7 +2770,9 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             // out first whatever their average; the sum only orders the chunks of the next frame.)
             const uint32_t segs1 = meta_depth(q.meta) < 0xFFFEu ? meta_depth(q.meta) + 1u : 0xFFFFu;
             const uint32_t segs = segs1 > kLongFrom ? (segs1 * kLongWeight < 0xFFFFu ? segs1 * kLongWeight : 0xFFFFu) : segs1;
-            const unsigned long long before = atomicAdd(acc + 3, 1ull | (static_cast<unsigned long long>(segs) << 32));
+            uint32_t one = 1u;  // (made here, as fresh64's words are: the pair's constant half otherwise lives -- in the COMPACT variant: in scratch -- all kernel long)
+            asm volatile("" : "+v"(one));
+            const unsigned long long before = atomicAdd(acc + 3, one | (static_cast<unsigned long long>(segs) << 32));
             completed = static_cast<uint32_t>(before) + 1u == a.spp;
         }
         unsigned long long done_mask = __ballot(completed);  // (0-2 lanes per call at a hundred samples per pixel)
@@ -2977,7 +2995,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     cur_pix = pix;
                     ++pool_next;
                     cur_s = 0u;
-                    if (lane < kAccWords) lds_acc[cur_entry * kAccWords + lane] = 0ull;
+                    if (lane < kAccWords) lds_acc[cur_entry * kAccWords + lane] = fresh64(0u);
                     if (lane == kAccWords) lds_pix[cur_entry] = pix | (cur_line << kPixLineShift);
                 }
                 const uint32_t n = want - served < a.spp - cur_s ? want - served : a.spp - cur_s;
@@ -3057,8 +3075,9 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     ps.active = lane < granted;
                     if (ps.active) {
                         camera_path(pa, gen_col, gen_row, pa.sample_offset + gen_s, ps.p);
-                        ++n_paths;
+                        if constexpr (!kWaveCounts) ++n_paths;
                     }
+                    if constexpr (kWaveCounts) wave_paths += granted;
                     DBG_ADD(dbg_pass[7], lane == 0u ? DBG_STAMP() - tp0 : 0ull);  // camera_path
                     float pb;
                     int pb_i;
@@ -3399,16 +3418,17 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     // counters (a global atomic is a 64-byte memory-side request: three per wave were 0.6 MB per frame).  A wave's sums
     // reach LDS before its arrival tick (its LDS operations are performed in order), so the last arrival sees them all.
     const PathArgs ea = reload_path_args();  // (cold: the counter blocks)
-    unsigned long long tests64 = n_tests;
     bool last_group = false;
-    for (int off = 32; off > 0; off >>= 1) {
-        n_paths += __shfl_down(n_paths, off);
-        n_segments += __shfl_down(n_segments, off);
-        tests64 += __shfl_down(tests64, off);
+    // the lanes' counts summed on the DPP network, totals in lane 63 (rounds 1-4: __shfl_down, whose lane number the compiler took from the
+    // kernel's first block and kept -- spilled, in the COMPACT variant -- to this last one); a wave's tests in two halves: 64 x 2^32 does not fit
+    if constexpr (!kWaveCounts) {  // (the large-scene variants start every path in a pass)
+        n_paths = wave_inclusive_sum(n_paths);
+        n_segments = wave_inclusive_sum(n_segments);
     }
-    if (lane == 0u) {
-        atomicAdd(&wg_sums[0], static_cast<unsigned long long>(n_paths));
-        atomicAdd(&wg_sums[1], static_cast<unsigned long long>(n_segments));
+    const unsigned long long tests64 = (static_cast<unsigned long long>(wave_inclusive_sum(n_tests >> 16)) << 16) + wave_inclusive_sum(n_tests & 0xFFFFu);
+    if (lane == 63u) {
+        atomicAdd(&wg_sums[0], static_cast<unsigned long long>(kWaveCounts ? wave_paths : n_paths));
+        atomicAdd(&wg_sums[1], static_cast<unsigned long long>(kWaveCounts ? wave_segments : n_segments));
         atomicAdd(&wg_sums[2], tests64);
         // (release / acquire at workgroup scope on the arrival tick, and atomic reads of the sums: the ordering the last
         // wave relies on is in the code, not in how the LDS happens to execute a wave's operations)
@@ -3426,7 +3446,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
         ea.counters->clk_cycles = __builtin_readcyclecounter() - clk_start[0];  // (rtGetStats divides)
         ea.counters->clk_ticks = wall_clock64() - clk_start[1];
     }
-    last_group = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(last_group)) != 0u;
+    last_group = __builtin_amdgcn_readlane(static_cast<uint32_t>(last_group), 63) != 0u;  // (lane 63 holds the sums and the tick)
     if (last_group && ea.next_counters != nullptr) {
         uint32_t* words = reinterpret_cast<uint32_t*>(ea.next_counters);
         for (uint32_t k = lane; k < sizeof(Counters) / 4u; k += 64u) words[k] = 0u;
