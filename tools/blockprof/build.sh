@@ -6,6 +6,7 @@
 #   large: path_persistent_kernel<false,true,true>  (C5's)
 #   flat : path_persistent_kernel<true,false,false> (C2's; the whole-file pass)
 #   compact: path_persistent_kernel<false,true,true,true> (C5's since round 5: four waves per SIMD; the whole-file pass)
+#   (a kernel that fills its waves' register budget -- large, compact -- lends the counters the unused lanes of its scalar-spill register)
 set -e
 WHICH=${1:-small}
 R=$(cd "$(dirname "$0")/../.." && pwd)

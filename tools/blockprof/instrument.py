@@ -36,6 +36,7 @@ nfv_i = next(i for i in range(desc, len(lines)) if ".amdhsa_next_free_vgpr" in l
 nfv = int(lines[nfv_i].split()[-1])
 acc_i = next(i for i in range(desc, len(lines)) if ".amdhsa_accum_offset" in lines[i])
 vS, vB = nfv, nfv + 1
+LS, LB = 0, 0      # first lane of the save area in vS, of the counter array's address in vB
 # the two spare registers must not cost a launch its largest workgroup: a 1024-thread group is four waves per SIMD, 512 registers between them
 meta = "\n".join(lines)
 mwg = re.search(r"\.max_flat_workgroup_size:\s*(\d+)\s*\n\s*\.name:\s*" + re.escape(name), meta)
@@ -43,6 +44,27 @@ if mwg:
     waves_per_simd = (int(mwg.group(1)) + 255) // 256
     alloc = (nfv + 2 + 7) // 8 * 8
     if waves_per_simd * alloc > 512:
+        # No room for two registers -- but a kernel that spills scalars keeps them in the lanes of a vector register of its own, which nothing
+        # else touches (v_writelane / v_readlane only, from the first block to the last), and it rarely uses all 64: lanes 56-63 of such a
+        # register do for the save area and the address.
+        body = lines[start:desc]
+        lane_use, other_use = {}, set()
+        for l in body:
+            mm = re.match(r"\s+v_writelane_b32\s+v(\d+),\s*\w+,\s*(\d+)", l) or re.match(r"\s+v_readlane_b32\s+\w+,\s*v(\d+),\s*(\d+)", l)
+            if mm:
+                lane_use.setdefault(int(mm.group(1)), set()).add(int(mm.group(2)))
+                continue
+            for r in re.findall(r"\bv(\d+)\b", l.split(";")[0]):
+                other_use.add(int(r))
+            for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", l.split(";")[0]):
+                other_use.update(range(int(a), int(b) + 1))
+        spare = [r for r, ls in lane_use.items() if r not in other_use and max(ls) < 56]
+        if spare:
+            vS = vB = spare[0]
+            LB, LS = 56, 58
+            nfv -= 2  # (the descriptor keeps its register count)
+            print(f"blockprof: no room for two registers more; lanes 56-63 of v{vS} (scalar spills in lanes 0-{max(lane_use[vS])}) take their place")
+    if vS != vB and waves_per_simd * alloc > 512:
         sys.exit(f"blockprof: {name} may run {mwg.group(1)}-thread groups ({waves_per_simd} waves per SIMD) and uses {nfv} VGPRs: two more would not fit "
                  f"512 registers per SIMD lane -- the launch would be refused (HSA_STATUS_ERROR_INVALID_ISA).  Not instrumented.")
 lines[nfv_i] = f"\t\t.amdhsa_next_free_vgpr {nfv + 2}"
@@ -60,10 +82,10 @@ def writes_exec(op, rest):
 
 def counter_code_lanes(b):
     # s3: SCC while s_bcnt1 overwrites it; s[4:5]: the lanes of EXEC as a 64-bit addend
-    sv = [f"\tv_writelane_b32 v{vS}, s{k}, {k}" for k in range(6)]
-    rs = [f"\tv_readlane_b32 s{k}, v{vS}, {k}" for k in range(6)]
+    sv = [f"\tv_writelane_b32 v{vS}, s{k}, {LS + k}" for k in range(6)]
+    rs = [f"\tv_readlane_b32 s{k}, v{vS}, {LS + k}" for k in range(6)]
     return [f"\t; ---- blockprof: block {b}", "\ts_waitcnt lgkmcnt(0)"] + sv + [
-            "\ts_cselect_b32 s3, 1, 0", f"\tv_readlane_b32 s0, v{vB}, 0", f"\tv_readlane_b32 s1, v{vB}, 1", "\ts_mov_b32 s2, 1", "\ts_mov_b32 s5, 0",
+            "\ts_cselect_b32 s3, 1, 0", f"\tv_readlane_b32 s0, v{vB}, {LB}", f"\tv_readlane_b32 s1, v{vB}, {LB + 1}", "\ts_mov_b32 s2, 1", "\ts_mov_b32 s5, 0",
             "\ts_nop 4", "\ts_bcnt1_i32_b64 s4, exec",
             f"\ts_atomic_add s2, s[0:1], 0x{b * STRIDE:x}", f"\ts_atomic_add_x2 s[4:5], s[0:1], 0x{b * STRIDE + 8:x}", "\ts_waitcnt lgkmcnt(0)",
             "\ts_cmp_lg_u32 s3, 0"] + rs + ["\ts_nop 4"]
@@ -75,10 +97,10 @@ def counter_code(b):
     # (the first wait: a scalar load still in flight may have s0..s2 as its destination -- saved before it lands and restored after, they
     # would lose what it loaded)
     return [f"\t; ---- blockprof: block {b}", "\ts_waitcnt lgkmcnt(0)",
-            f"\tv_writelane_b32 v{vS}, s0, 0", f"\tv_writelane_b32 v{vS}, s1, 1", f"\tv_writelane_b32 v{vS}, s2, 2",
-            f"\tv_readlane_b32 s0, v{vB}, 0", f"\tv_readlane_b32 s1, v{vB}, 1", "\ts_mov_b32 s2, 1", "\ts_nop 4",
+            f"\tv_writelane_b32 v{vS}, s0, {LS}", f"\tv_writelane_b32 v{vS}, s1, {LS + 1}", f"\tv_writelane_b32 v{vS}, s2, {LS + 2}",
+            f"\tv_readlane_b32 s0, v{vB}, {LB}", f"\tv_readlane_b32 s1, v{vB}, {LB + 1}", "\ts_mov_b32 s2, 1", "\ts_nop 4",
             f"\ts_atomic_add s2, s[0:1], 0x{b * STRIDE:x}", "\ts_waitcnt lgkmcnt(0)",
-            f"\tv_readlane_b32 s0, v{vS}, 0", f"\tv_readlane_b32 s1, v{vS}, 1", f"\tv_readlane_b32 s2, v{vS}, 2", "\ts_nop 4"]
+            f"\tv_readlane_b32 s0, v{vS}, {LS}", f"\tv_readlane_b32 s1, v{vS}, {LS + 1}", f"\tv_readlane_b32 s2, v{vS}, {LS + 2}", "\ts_nop 4"]
 
 
 out = lines[:start + 1]
@@ -105,7 +127,7 @@ for l in lines[start + 1:end]:
             out += ["\t; ---- blockprof: address of Counters::block_counts into lanes 0, 1 of the spare register",
                     f"\ts_load_dwordx2 s[90:91], s[0:1], 0x{off_counters:x}", "\ts_waitcnt lgkmcnt(0)",
                     f"\ts_add_u32 s90, s90, 0x{off_blocks:x}", "\ts_addc_u32 s91, s91, 0",
-                    f"\tv_writelane_b32 v{vB}, s90, 0", f"\tv_writelane_b32 v{vB}, s91, 1", "\ts_nop 4"]
+                    f"\tv_writelane_b32 v{vB}, s90, {LB}", f"\tv_writelane_b32 v{vB}, s91, {LB + 1}", "\ts_nop 4"]
             prologue_done = True
         out += counter_code(len(blocks))
         blocks.append([])

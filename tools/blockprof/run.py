@@ -26,8 +26,9 @@ else:
     sph, mat = V.make_cover_scene(1, 11)
     cam = V.make_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, w / h, 0.1, 10.0)
 out = {}
-for tag, so in (("shipped", "librtiow_hip.so"), ("blockprof", "librtiow_hip_blk.so")):
-    lib = C.CDLL(os.path.join(ROOT, "vulkan-rtiow_amd", so))
+# (BLOCKPROF_LIB: another instrumented library than the last one built, e.g. a copy kept of each of several builds)
+for tag, so in (("shipped", "librtiow_hip.so"), ("blockprof", os.environ.get("BLOCKPROF_LIB", "librtiow_hip_blk.so"))):
+    lib = C.CDLL(so if os.path.isabs(so) else os.path.join(ROOT, "vulkan-rtiow_amd", so))
     for name, (res, at) in api.SIGNATURES.items():
         getattr(lib, name).restype = res
         getattr(lib, name).argtypes = at
