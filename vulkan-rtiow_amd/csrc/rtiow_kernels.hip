@@ -7,12 +7,13 @@
 //                           image sizes; RtParams.kernel = 1: the form the row kernel is checked against)
 //   path_pixel_kernel       PATH mode v1 (RtParams.kernel 1): one lane per pixel, spp + bounce loops inside, sphere
 //                           list staged in LDS once per workgroup; kept as a cross-check and ablation
-//   path_persistent_kernel  PATH mode v2, six instantiations <shading records in LDS?, clustered list?, flat-axis boxes?>:
+//   path_persistent_kernel  PATH mode v2, eight instantiations <shading records in LDS?, clustered list?, flat-axis boxes?, compact per-wave area?>:
 //                           persistent waves, two path slots per lane, per-XCD pixel queues, LDS accumulators, in-kernel
 //                           resolve.  <., false, false> walks the flat sphere list (kernel 2; default below 64 spheres),
 //                           <., true, .> the two-level clustered list (kernel 3; default from 64 spheres on) with camera
 //                           rays traced in the primary pass (primary_trace: kernel 4 forces it at any spp); <., true, true>
-//                           tests the cluster boxes without the axis they all share (scenes that stand on a plane)
+//                           tests the cluster boxes without the axis they all share (scenes that stand on a plane); <false, true, ., true>
+//                           is the large-scene variant at four waves per SIMD (launch_path takes it where it keeps more waves per CU)
 //   order_chunks_kernel     the next frame's chunk sequence from this frame's per-chunk costs (cost-ordered dequeue)
 //   arith_kernel            one operation per element: the arithmetic conformance probe of rtSelfTestArith
 //   (deinterleave_kernel, the multi-GPU frame assembly, lives in rtiow_multi.hip)
@@ -2761,6 +2762,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
 #ifdef RTIOW_DEBUG_TIMELINE
             if (tl_dry != 0ull && meta_depth(q.meta) + 1u > tl_deepest) tl_deepest = meta_depth(q.meta) + 1u;
             if (meta_depth(q.meta) + 1u >= 40u) tl_deep_end = wall_clock64();
+            atomicAdd(&a.counters->tl_depth_hist[meta_depth(q.meta) + 1u < 63u ? meta_depth(q.meta) + 1u : 63u], 1ull);
 #endif
             q.active = false;
             unsigned long long* acc = lds_acc + meta_entry(q.meta) * kAccWords;
@@ -3648,7 +3650,8 @@ __global__ __launch_bounds__(1024) void order_chunks_kernel(unsigned long long* 
 // ms against the default scheduler).  Round 3: iterative-minreg brings the flat-axis variant to 136 registers; held to 128
 // (-DRTIOW_SMALL_WAVES_PER_EU=4) it spilled 13 of them (28 by the end of the round) and runs FOUR waves per SIMD -- launch_path
 // then finds two groups of 512 threads per CU: cover frame 7.95 -> 7.19 ms, one eighth of it 1.33 -> 1.26 (interleaved A/B,
-// tools/ab_bench.py; iterative-minreg at three waves: 8.48).  Round 4: with Slot's bookkeeping in one register and one base for the per-wave LDS areas, none.  The large-scene variants spill 115 registers at 128 and have no LDS for sixteen
+// tools/ab_bench.py; iterative-minreg at three waves: 8.48).  Round 4: with Slot's bookkeeping in one register and one base for the per-wave LDS areas, none;
+// round 5: ONE group of 1024 threads per CU (one copy of the scene: RTIOW_PASS_KEEP), the default scheduler, 113 / 120 registers.  The large-scene variants spill 115 registers at 128 and have no LDS for sixteen
 // waves' buffers, the flat-list kernels (95 registers) gain nothing: they stay with the default scheduler.
 // Round 4: the large-scene variants get a pass of their own too (-DRTIOW_TU_LARGE_CLUSTERED, rtiow_kernels_large.o) under iterative-ilp: at 148
 // registers (three waves per SIMD allow 168) it spills nothing and the 4099-sphere scene renders 1.8 % faster than under the default
