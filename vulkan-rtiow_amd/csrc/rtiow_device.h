@@ -68,7 +68,7 @@ struct Counters {
     // deepest path finished after dry, when the last path of 40+ segments finished
     unsigned int tl_wave[8192][8];
     unsigned long long tl_bucket[5][4];  // sparse iterations by paths held (1-2, 3-4, 5-8, 9-16, 17-32): count, ticks, trace cycles, shade cycles
-    unsigned long long tl_depth_hist[64];  // finished paths by the segments they took (63: that many or more)
+    unsigned long long tl_depth_hist[64];  // finished paths by the segments they took, from 8 on (63: that many or more)
 #endif
 #ifdef RTIOW_BLOCK_COUNTERS
     // tools/blockprof builds only: one execution counter per basic block of the instrumented kernel, each on a 128-byte line of its own
