@@ -602,8 +602,10 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
             for (int b = 0; b < 9; ++b) fprintf(stderr, " %u", c.tl_live_at_dry_hist[b]);
             fprintf(stderr, "; of the waves dry > 100 us after the first:");
             for (int b = 0; b < 9; ++b) fprintf(stderr, " %u", c.tl_late_dry_live_hist[b]);
+#ifdef RTIOW_DEBUG_DEPTH_HIST
             fprintf(stderr, "\npaths by segments taken (8, 9, ... 62, 63+):");
             for (int b = 8; b < 64; ++b) fprintf(stderr, " %llu", c.tl_depth_hist[b]);
+#endif
             fprintf(stderr, "\nfrom the first sparse iteration on: %llu iterations, %.2f us each, %.1f paths each\n", c.tl_sparse_iters_sum,
                     c.tl_sparse_iters_sum ? c.tl_sparse_ticks_sum * 0.01 / c.tl_sparse_iters_sum : 0.0,
                     c.tl_sparse_iters_sum ? double(c.tl_sparse_paths_sum) / c.tl_sparse_iters_sum : 0.0);

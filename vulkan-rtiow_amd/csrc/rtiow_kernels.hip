@@ -2762,8 +2762,11 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
 #ifdef RTIOW_DEBUG_TIMELINE
             if (tl_dry != 0ull && meta_depth(q.meta) + 1u > tl_deepest) tl_deepest = meta_depth(q.meta) + 1u;
             if (meta_depth(q.meta) + 1u >= 40u) tl_deep_end = wall_clock64();
-            // (from 8 segments on, 1.5 % of the cover frame's paths: one atomic per path on the few words of the short ones took 0.9 s a frame)
+#ifdef RTIOW_DEBUG_DEPTH_HIST
+            // (a build of its own, EXTRA=-DRTIOW_DEBUG_DEPTH_HIST on top of `make tl`: atomics on a handful of words -- a frame takes three times
+            // as long with them, from 8 segments on; with one per path, 0.9 s -- so the timeline build proper does without)
             if (meta_depth(q.meta) + 1u >= 8u) atomicAdd(&a.counters->tl_depth_hist[meta_depth(q.meta) + 1u < 63u ? meta_depth(q.meta) + 1u : 63u], 1ull);
+#endif
 #endif
             q.active = false;
             unsigned long long* acc = lds_acc + meta_entry(q.meta) * kAccWords;
