@@ -584,3 +584,17 @@ def test_blockprof_instruments_the_default_kernel_and_one_without_spare_register
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "blockprof", "relax.py"), os.path.join(bdir, "lanes_test.s"), os.path.join(bdir, "lanes_test.o")],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "trampolines" in res.stdout, res.stdout[-500:] + res.stderr[-2000:]
+
+
+def test_a_rebuild_elsewhere_is_the_shipped_library_byte_for_byte(tmp_path):
+    """csrc/Makefile names every object's compilation unit id itself (-cuid: hipcc would derive it from the command line, output path included),
+    so the library is the same bytes wherever it is built: what `make OUT=/somewhere/else.so` gives is the file the tests, the bench line and the
+    profiles ran on."""
+    import subprocess
+    lib = os.path.join(ROOT, "vulkan-rtiow_amd", "librtiow_hip.so")
+    if not os.path.exists("/opt/rocm/bin/hipcc") or not os.path.exists(lib):
+        pytest.skip("no hipcc / no built library")
+    out = tmp_path / "elsewhere" / "other_name.so"
+    res = subprocess.run(["make", "-s", "-j8", "-C", os.path.join(ROOT, "vulkan-rtiow_amd", "csrc"), f"OUT={out}"], capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert open(out, "rb").read() == open(lib, "rb").read()
