@@ -166,12 +166,11 @@ int rtAbiVersion(void);
 /* ---- scene upload: BUILD-SPEC extension of the descriptor writes at
  *      RTCHAP06/main.cpp:140-151 (the reference binds no scene buffer) -----
  *      LIMIT: 1 <= n_spheres <= 6144, else RT_ERR_INVALID.  Every persistent kernel keeps the whole sphere list in the LDS of
- *      a CU (160 KB: 20 bytes per list slot + the cluster boxes + 6 KB of private area per wave), which is where north_star
- *      asks for it; 6144 spheres are 123 KB of list, the most that still leaves one 256-thread group its areas.  BASELINE's
- *      largest scene has 4099.  Inside the limit the speed has two steps (profiles/r04_scene_size_sweep.txt): up to ~510
- *      spheres the shading records share the LDS and sixteen waves run per CU; up to ~4600 twelve waves (one 768-thread group
- *      around one copy of the list); beyond that the list leaves room for eight, then four waves -- a 5185-sphere scene takes
- *      1.5x the time of a 4099-sphere one. */
+ *      a CU (160 KB: 18 bytes per list slot + the cluster boxes + 4.4 - 6 KB of private area per wave), which is where north_star
+ *      asks for it; 6144 spheres are 118 KB of list.  BASELINE's largest scene has 4099.  Inside the limit the speed has steps
+ *      (profiles/r05_scene_size_sweep.txt): up to ~510 spheres the shading records share the LDS; up to ~4600 spheres sixteen
+ *      waves run per CU around one copy of the list, with fewer and fewer waiting camera paths each; beyond that the list leaves
+ *      room for fewer waves -- fourteen at 5185 spheres, ten at 6086, which takes 1.6x the time of a 4099-sphere scene. */
 int rtSetScene(RtContext* ctx, const RtSphere* spheres, const RtMaterial* materials,
                uint32_t n_spheres);
 

@@ -211,12 +211,15 @@ constexpr double kRangeOneLevel = 2.0, kRangeTwoLevel = 0.6, kRangeFloor = 0.25;
 // scene's own range -- kRangeTwoLevel if it gets super-clusters, kRangeOneLevel if not -- decided inside, before a box is made
 void build_clusters(const RtSphere* spheres, uint32_t n, double range_diags, ClusterScene& out);
 unsigned long long cluster_build_count();  // calls of build_clusters in this process so far (tests: a scene is boxed once)
+// A slot's original sphere index as the kernels keep it in LDS: 16 bits (rtSetScene caps a scene at 6144 spheres; round 5 -- 32 bits before:
+// 8 KB of C5's 87 KB of lists, twelve of a 6000-sphere scene's 128)
+typedef unsigned short SlotIndex;
 // Does the clustered list fit the LDS of a CU beside the per-wave areas of one 256-thread group: 2 = with its super-cluster
 // level, 1 = without it (launch_path then drops the level), 0 = not at all (flat list).  Shared by launch_path and rtSetScene.
 inline int clustered_levels_that_fit(uint32_t n_cslots, uint32_t n_clusters, uint32_t n_super, bool flat) {
     const uint32_t box_bytes = flat ? 16u : 32u;
     auto fits = [&](uint32_t supers) {
-        return static_cast<size_t>(n_cslots) * 20u + static_cast<size_t>(n_clusters + supers) * box_bytes +
+        return static_cast<size_t>(n_cslots) * (16u + sizeof(SlotIndex)) + static_cast<size_t>(n_clusters + supers) * box_bytes +
                    kGroupLdsBytes + 4u * (kWaveAccBytes + kWavePixBytes + kWaveLineBytes + wave_item_bytes(supers != 0u)) <= kLdsPerCu;
     };
     return fits(n_super) ? 2 : (fits(0u) ? 1 : 0);

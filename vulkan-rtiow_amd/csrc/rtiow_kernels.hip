@@ -1152,9 +1152,9 @@ DI void trace_slots(const float4* lds, uint32_t n_pad, uint32_t n, Slot (&sl)[R]
 // index; the wave reduction takes the minimum of (root bits << 32 | index), which orders positive
 // floats numerically and breaks ties towards the lower index as well.
 // `list` is the flat list (idx_map == nullptr: slot == sphere index) or the clustered list's slots
-// (idx_map gives the original index, 0xFFFFFFFF for padding).  Results: best_i = slot, best_o = index.
+// (idx_map gives the original index, 0xFFFF for padding).  Results: best_i = slot, best_o = index.
 template <int R>
-DI void trace_sparse(const float4* list, const uint32_t* idx_map, uint32_t n_slots, uint32_t n, Slot (&sl)[R],
+DI void trace_sparse(const float4* list, const SlotIndex* idx_map, uint32_t n_slots, uint32_t n, Slot (&sl)[R],
                      float (&best)[R], int (&best_i)[R], uint32_t (&best_o)[R]) {
     const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
@@ -1221,7 +1221,7 @@ DI void trace_sparse(const float4* list, const uint32_t* idx_map, uint32_t n_slo
 // The slab test only has to be conservative (rtiow_clusters.cpp sizes the boxes for its rounding and
 // the exact test's), so it may use v_rcp_f32 and any operation order; it never decides a hit.
 // key = root bits << 32 | original index << 16 | slot (both below 65536: rtSetScene caps the scene)
-DI void examine_keyed(const float4* slots, const uint32_t* idx_map, uint32_t slot, const float ox, const float oy,
+DI void examine_keyed(const float4* slots, const SlotIndex* idx_map, uint32_t slot, const float ox, const float oy,
                       const float oz, const float dx, const float dy, const float dz, unsigned long long& key) {
     const float4 s = slots[slot];
     const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
@@ -1243,7 +1243,7 @@ DI void examine_keyed(const float4* slots, const uint32_t* idx_map, uint32_t slo
 }
 
 // the 16 members of the cluster whose slots start at `base`, for one ray
-DI void examine_cluster(const float4* slots, const uint32_t* idx_map, uint32_t base, uint32_t lane, const float ox,
+DI void examine_cluster(const float4* slots, const SlotIndex* idx_map, uint32_t base, uint32_t lane, const float ox,
                         const float oy, const float oz, const float dx, const float dy, const float dz,
                         unsigned long long& key) {
     static_assert(kClusterSize == 16u && kClusterStride == 16u, "the member order below is an XOR on four bits of a cluster's first slot");
@@ -1462,7 +1462,7 @@ DI void fetch_item_ray(const Slot (&sl)[R], uint32_t item, float& ox, float& oy,
 // order-independent, so the result is the one the per-lane walk gives.
 // An item is lane | slot << 6 | (cluster - cluster_base) << 7.
 template <int R>
-DI void consume_items(const float4* slots, const uint32_t* idx_map, const PathArgs& a, const uint16_t* items,
+DI void consume_items(const float4* slots, const SlotIndex* idx_map, const PathArgs& a, const uint16_t* items,
                       uint32_t total, uint32_t cluster_base, const Slot (&sl)[R], unsigned long long* results,
                       uint32_t& n_tests, uint32_t& dbg_slow_trips) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -1484,7 +1484,7 @@ DI void consume_items(const float4* slots, const uint32_t* idx_map, const PathAr
 }
 
 // every cluster of cm (bit 31 = cluster g0), lane by lane: the fallback when a work list overflows
-DI void walk_clusters(const float4* slots, const uint32_t* idx_map, const PathArgs& a, uint32_t cm, uint32_t g0,
+DI void walk_clusters(const float4* slots, const SlotIndex* idx_map, const PathArgs& a, uint32_t cm, uint32_t g0,
                       const Path& p, unsigned long long& key, uint32_t& n_tests) {
     const uint32_t lane = threadIdx.x & 63u;
     while (cm) {
@@ -1501,7 +1501,7 @@ DI void walk_clusters(const float4* slots, const uint32_t* idx_map, const PathAr
 // without that level, which is a third of this function and would otherwise weigh on its register allocation.
 // FLAT: the boxes are tested without their flat axis (slab_gap_flat; `bounds` then holds one float4 per box).
 template <int R, bool SUPER, bool FLAT>
-DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const float4* bounds, const PathArgs& a,
+DI void trace_clustered(const float4* slots, const SlotIndex* idx_map, const float4* bounds, const PathArgs& a,
                         uint16_t* items, unsigned long long* results,
                         Slot (&sl)[R], float (&best)[R], int (&best_i)[R], uint32_t (&best_o)[R],
                         uint32_t& n_tests, uint32_t& dbg_slow_trips, uint32_t& dbg_cands,
@@ -1561,7 +1561,7 @@ DI void trace_clustered(const float4* slots, const uint32_t* idx_map, const floa
 #pragma unroll
             for (uint32_t u = 0; u < 4u; ++u) {
                 s4[u] = slots[j + u];                        // wave-uniform addresses: LDS broadcast
-                lo4[u] = (idx_map[j + u] << 16) | (j + u);   // low word of the key: original index, slot
+                lo4[u] = (static_cast<uint32_t>(idx_map[j + u]) << 16) | (j + u);   // low word of the key: original index, slot
             }
 #pragma unroll
             for (uint32_t u = 0; u < 4u; ++u) {
@@ -1937,7 +1937,7 @@ DI SparseRay load_sparse_ray(const float* rays, uint32_t p) {
 }
 
 // consumes `count` (path, cluster) items: sixteen lanes per item, one member each
-DI void sparse_members(const float4* slots, const uint32_t* idx_map, const PathArgs& a, const uint16_t* items,
+DI void sparse_members(const float4* slots, const SlotIndex* idx_map, const PathArgs& a, const uint16_t* items,
                        uint32_t count, const float* rays, unsigned long long* keys, uint32_t& n_tests) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = count * kClusterSize;
@@ -1957,7 +1957,7 @@ DI void sparse_members(const float4* slots, const uint32_t* idx_map, const PathA
 }
 
 template <int R, bool SUPER, bool FLAT>
-DI void trace_sparse_parallel(const float4* slots, const uint32_t* idx_map, const float4* bounds, const PathArgs& a,
+DI void trace_sparse_parallel(const float4* slots, const SlotIndex* idx_map, const float4* bounds, const PathArgs& a,
                               uint16_t* items, unsigned long long* results, Slot (&sl)[R], float (&best)[R],
                               int (&best_i)[R], uint32_t (&best_o)[R], uint32_t& n_tests) {
     static_assert(kSparseParMax == 32u, "items carry the path in five bits");
@@ -2120,7 +2120,7 @@ DI void examine_loaded(const float4& s, uint32_t orig, uint32_t slot, const Spar
 }
 
 // consumes `count` (path, cluster) items: sixteen lanes per item, one member each, four items per lane and trip
-[[maybe_unused]] DI void sparse_members4(const float4* slots, const uint32_t* idx_map, const PathArgs& a, const uint16_t* items,
+[[maybe_unused]] DI void sparse_members4(const float4* slots, const SlotIndex* idx_map, const PathArgs& a, const uint16_t* items,
                         uint32_t count, const float* rays, unsigned long long* keys, uint32_t& n_tests) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = count * kClusterSize;
@@ -2156,7 +2156,7 @@ DI void examine_loaded(const float4& s, uint32_t orig, uint32_t slot, const Spar
 }
 
 template <bool FLAT>
-DI void trace_sparse_batched(const float4* slots, const uint32_t* idx_map, const float4* bounds, const PathArgs& a,
+DI void trace_sparse_batched(const float4* slots, const SlotIndex* idx_map, const float4* bounds, const PathArgs& a,
                              uint16_t* items, unsigned long long* results, Slot& sl, float& best, int& best_i,
                              uint32_t& best_o, uint32_t& n_tests) {
     static_assert(kSparseBatchMax <= kSparseParMax && 4u * 64u <= kItemCap, "items carry the path in five bits; a trip's items fit the list");
@@ -2413,10 +2413,10 @@ HDI bool cone_reaches_sphere(const PathArgs& a, const PersistArgs& g, const Cone
 }
 
 // exact test of the sphere in slot `slot` (wave-uniform: LDS broadcast) for the lane's own ray, branch-free
-[[maybe_unused]] DI void exact_keyed_lockstep(const float4* slots, const uint32_t* idx_map, uint32_t slot, const Path& p,
+[[maybe_unused]] DI void exact_keyed_lockstep(const float4* slots, const SlotIndex* idx_map, uint32_t slot, const Path& p,
                              unsigned long long& key) {
     const float4 s = slots[slot];
-    const uint32_t lo = (idx_map[slot] << 16) | slot;
+    const uint32_t lo = (static_cast<uint32_t>(idx_map[slot]) << 16) | slot;
     const float ocx = p.o.x - s.x, ocy = p.o.y - s.y, ocz = p.o.z - s.z;
     const float hb = fma_(ocz, p.du.z, fma_(ocy, p.du.y, ocx * p.du.x));
     const float cc = fma_(ocz, ocz, fma_(ocy, ocy, fma_(ocx, ocx, -s.w)));
@@ -2435,7 +2435,7 @@ HDI bool cone_reaches_sphere(const PathArgs& a, const PersistArgs& g, const Cone
 // those clusters (and the large spheres) the cones reach; what is left, typically the ground and a sphere or two, takes
 // the exact test in lock-step.  Same test, same key, same minimum as trace_clustered for every sphere that can be hit.
 template <bool SUPER, bool FLAT>
-DI void primary_trace(const float4* slots, const uint32_t* idx_map, const float4* bounds, const PathArgs& a,
+DI void primary_trace(const float4* slots, const SlotIndex* idx_map, const float4* bounds, const PathArgs& a,
                       const PersistArgs& g, const Path& p, bool active, const uint32_t (&span_col)[kPassSpans],
                       const uint32_t (&span_len)[kPassSpans], const uint32_t (&span_row)[kPassSpans], uint32_t n_spans, float& best, int& best_i,
                       uint32_t& best_o, uint32_t& n_tests, unsigned long long& dbg_trips) {
@@ -2610,7 +2610,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     // The shader clock this frame ran at, from one wave's two clocks (shader cycles, and the constant 100 MHz counter): the stamps
     // are parked in LDS, not in registers.  (The fp32 peak a frame can be rated against is 157.3 TFLOP/s at 2.4 GHz;
     // under this kernel the part holds about 2.0: bench.py prints both.)
-    uint32_t* lds_cidx = reinterpret_cast<uint32_t*>(lds_spheres + g.n_pad);
+    SlotIndex* lds_cidx = reinterpret_cast<SlotIndex*>(lds_spheres + g.n_pad);  // (n_pad is a multiple of 16: the boxes behind stay 16-byte aligned)
     float4* lds_cbounds = reinterpret_cast<float4*>(lds_cidx + (ACCEL ? g.n_pad : 0u));
     // (boxes: centre + half extent, two float4 each; FLAT: without the flat axis, one float4 each)
     float4* lds_shade = lds_cbounds + (ACCEL ? (FLAT ? 1u : 2u) * (a.n_clusters + a.n_super) : 0u);
@@ -2643,7 +2643,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     if (ACCEL) {
         for (uint32_t i = threadIdx.x; i < g.n_pad; i += blockDim.x) {
             lds_spheres[i] = a.cslots[i];
-            lds_cidx[i] = a.cidx[i];
+            lds_cidx[i] = static_cast<SlotIndex>(a.cidx[i]);  // (padding: 0xFFFF)
         }
         if (FLAT) {  // (a list of their own in HBM, clusters first: launch_path may have dropped the super level)
             for (uint32_t i = threadIdx.x; i < a.n_clusters + a.n_super; i += blockDim.x) lds_cbounds[i] = a.cbounds2[i];
@@ -3839,7 +3839,7 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
     // 2 KiB of pixel accumulator entries and 0.5 KiB of line buffers per wave (clustered: + 2-3 KiB of work lists
     // and result keys).
     const size_t lds_geo = static_cast<size_t>(g.n_pad) * sizeof(float4) +
-                           (accel ? static_cast<size_t>(g.n_pad) * 4u + static_cast<size_t>(a.n_clusters + a.n_super) * box_bytes : 0u);
+                           (accel ? static_cast<size_t>(g.n_pad) * sizeof(SlotIndex) + static_cast<size_t>(a.n_clusters + a.n_super) * box_bytes : 0u);
     // (a scene with super-clusters -- more than kSuperFrom clusters, i.e. more than 512 small spheres: 30 KB at least -- is never a
     // small one: the small-scene kernels are compiled without that level)
     const bool shade_lds = a.n_super == 0u && lds_geo + static_cast<size_t>(a.n) * sizeof(ShadeRec) <= 28u * 1024u &&
@@ -3911,7 +3911,9 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
             void (*fn)(PathArgs, PersistArgs) = compact ? compact_fn : kernel_fn;
             // as many pass records as the LDS has room for without losing a wave: most first, so that a tie in waves keeps the most records
             for (uint32_t keep = accel ? keep_env : 0u;; keep = keep >= 8u ? keep - 8u : 0u) {
-                for (uint32_t t = 256u; t <= (compact ? 1024u : t_max); t += 256u) {
+                // (large scenes: wave by wave -- a 6086-sphere scene's lists leave room for ten waves' areas, not for twelve: 640 threads, where
+                // steps of 256 stopped at 512; the other kernels keep whole multiples of the four SIMDs)
+                for (uint32_t t = 256u; t <= (compact ? 1024u : t_max); t += (accel && !shade_lds ? 64u : 256u)) {
                     if (pinned != 0u && t != pinned) continue;
                     const size_t need = lds_scene + kGroupLdsBytes + static_cast<size_t>(t / 64u) * wave_bytes_of(keep, compact);
                     if (need > kLdsPerCu) continue;
@@ -3936,6 +3938,9 @@ hipError_t launch_path(const PathArgs& args, uint32_t kernel, uint32_t max_take,
         c.threads = threads; c.per_cu = per_cu; c.lds = lds; c.pass_keep = g.pass_keep; c.wave_bytes = g.wave_bytes;
         c.chosen = reinterpret_cast<const void*>(chosen_fn);
     }
+    if (debug_knob("RTIOW_DEBUG_LAUNCH"))  // (knobs builds: what the search chose -- tools/grid_stats.py)
+        fprintf(stderr, "launch: %u spheres, %u-thread groups x %d per CU = %d waves per CU, %zu B of LDS a group (%zu the lists), %u pass records a wave%s\n", a.n, threads,
+                per_cu, per_cu * static_cast<int>(threads / 64u), lds, lds_scene, g.pass_keep, chosen_fn == compact_fn && compact_fn != nullptr ? ", compact areas" : "");
     kernel_fn = chosen_fn;
     // camera paths a pass may make: one per lane, and no more than the records hold (those beyond pass_keep lie in the
     // work-list area: 42 of them, or all 64 in the two-level one)
