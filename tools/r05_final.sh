@@ -17,5 +17,6 @@ RTIOW_LIB=$PWD/vulkan-rtiow_amd/librtiow_hip_dbg.so RTIOW_DEBUG_HIST=1 python to
 RTIOW_DEBUG_HIST=1 RTIOW_LIB=$PWD/vulkan-rtiow_amd/librtiow_hip_tl.so python tools/timeline.py 8 1 > $O/r05_timeline.txt 2>&1; grep -E "iterations after|queue 0 head|G=" $O/r05_timeline.txt | cut -c1-200
 python tools/inflight.py > $O/r05_inflight.txt 2>&1; tail -8 $O/r05_inflight.txt
 BENCH_ONE_DEVICE=1 BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 > $O/r05_bench_2rank_gloo_rehearsal_one_gpu.json 2> $O/r05_bench_2rank.err; grep "^{\"metric" $O/r05_bench_2rank_gloo_rehearsal_one_gpu.json | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(\"2-rank gloo rehearsal\", d[\"ms_per_step\"], d[\"config\"][\"gathered_frame_vs_single_gpu_frame\"], d[\"frame_check\"])" || tail -5 $O/r05_bench_2rank.err
-GRIDS=11,12,14,16,20,22,24,28,30,32,34,36,39 python tools/grid_stats.py 2>&1 | grep grid > $O/r05_scene_size_sweep.txt; cat $O/r05_scene_size_sweep.txt
+# (the knobs build -- the shipped kernels -- for RTIOW_DEBUG_LAUNCH: what launch_path chose for each scene)
+RTIOW_LIB=$PWD/vulkan-rtiow_amd/librtiow_hip_knobs.so RTIOW_DEBUG_LAUNCH=1 GRIDS=11,12,14,16,20,22,24,28,30,32,34,36,38,39 python tools/grid_stats.py 2>&1 | grep "grid\|launch" | uniq > $O/r05_scene_size_sweep.txt; cat $O/r05_scene_size_sweep.txt
 python tools/ch_bandwidth.py 800x608 4096x4096 16384x8192 16384x16384 2> /dev/null | grep "^CH0" > $O/r05_ch_bandwidth_plain.txt; cat $O/r05_ch_bandwidth_plain.txt
