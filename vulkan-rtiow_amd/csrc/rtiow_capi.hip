@@ -606,6 +606,9 @@ int rtGetStats(RtContext* ctx, RtStats* out) {
             fprintf(stderr, "\npaths by segments taken (8, 9, ... 62, 63+):");
             for (int b = 8; b < 64; ++b) fprintf(stderr, " %llu", c.tl_depth_hist[b]);
 #endif
+            fprintf(stderr, "\nstart of the frame, per wave: entry -> scene staged, barrier passed %.2f us (max %.2f); then -> first pool fetched %.2f us -> first hand_out done %.2f us -> first camera rays made %.2f us (max %.2f; %llu waves)",
+                    c.tl_start_sum[0] * 0.01 / 4096.0, c.tl_start_max[0] * 0.01, c.tl_start_sum[2] ? c.tl_start_sum[3] * 0.01 / c.tl_start_sum[2] : 0.0,
+                    c.tl_start_sum[2] ? c.tl_start_sum[4] * 0.01 / c.tl_start_sum[2] : 0.0, c.tl_start_sum[2] ? c.tl_start_sum[1] * 0.01 / c.tl_start_sum[2] : 0.0, c.tl_start_max[1] * 0.01, c.tl_start_sum[2]);
             fprintf(stderr, "\nfrom the first sparse iteration on: %llu iterations, %.2f us each, %.1f paths each\n", c.tl_sparse_iters_sum,
                     c.tl_sparse_iters_sum ? c.tl_sparse_ticks_sum * 0.01 / c.tl_sparse_iters_sum : 0.0,
                     c.tl_sparse_iters_sum ? double(c.tl_sparse_paths_sum) / c.tl_sparse_iters_sum : 0.0);

@@ -68,6 +68,9 @@ struct Counters {
     // deepest path finished after dry, when the last path of 40+ segments finished
     unsigned int tl_wave[8192][8];
     unsigned long long tl_bucket[5][4];  // sparse iterations by paths held (1-2, 3-4, 5-8, 9-16, 17-32): count, ticks, trace cycles, shade cycles
+    unsigned long long tl_start_sum[5];    // per wave, 10 ns ticks: entry -> staged (barrier passed); staged -> first camera rays made; waves that made any;
+                                           // staged -> first pool fetched; staged -> first hand_out done
+    unsigned int tl_start_max[2];
     unsigned long long tl_depth_hist[64];  // finished paths by the segments they took, from 8 on (63: that many or more)
 #endif
 #ifdef RTIOW_BLOCK_COUNTERS

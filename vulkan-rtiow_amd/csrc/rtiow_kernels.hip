@@ -2592,6 +2592,9 @@ constexpr int kAccelMaxThreads = RTIOW_ACCEL_MAX_THREADS;
 template <bool SHADE_LDS, bool ACCEL, bool FLAT = false, bool COMPACT = false>
 __global__ __launch_bounds__(COMPACT ? 1024 : (ACCEL ? (SHADE_LDS ? RTIOW_SMALL_MAX_THREADS : kAccelMaxThreads) : 1024)) __attribute__((amdgpu_waves_per_eu(COMPACT ? 4 : (ACCEL && !SHADE_LDS ? RTIOW_LARGE_WAVES_PER_EU : RTIOW_SMALL_WAVES_PER_EU))))
 void path_persistent_kernel(PathArgs a, PersistArgs g) {
+#ifdef RTIOW_DEBUG_TIMELINE
+    const unsigned long long tl_entry = wall_clock64();  // (the wave's first instruction: what the scene's staging costs -- VERDICT r4's start-of-tile question)
+#endif
     static_assert(ACCEL || !FLAT, "only the clustered list has boxes");
     static_assert(!COMPACT || (ACCEL && !SHADE_LDS), "the compact per-wave area is for the large-scene clustered kernels");
     constexpr uint32_t kAccE = COMPACT ? kAccEntriesCompact : kAccEntries, kLineB = COMPACT ? kLineBufsCompact : kLineBufs;
@@ -2687,8 +2690,10 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
     [[maybe_unused]] bool exhausted = false; // the global queue has been drained
 #ifdef RTIOW_DEBUG_TIMELINE
     const unsigned long long tl_start = wall_clock64();
-    if (lane == 0u) atomicMax(&a.counters->not_t0, ~tl_start);
-    unsigned long long tl_dry = 0ull, tl_sparse = 0ull;
+    // (one wave per workgroup: with one atomic per WAVE -- 4096 on one word, which the memory side performs one after the other -- every wave's
+    // first load waited 30 us behind them, and the timeline showed a start-up cost that was its own)
+    if (threadIdx.x == 0u) atomicMax(&a.counters->not_t0, ~tl_start);
+    unsigned long long tl_dry = 0ull, tl_sparse = 0ull, tl_first_rays = 0ull, tl_first_pool = 0ull, tl_first_out = 0ull;  // (... first camera rays made, first pool fetched, first hand_out done)
     uint32_t tl_tail_iters = 0u, tl_sparse_iters = 0u, tl_sparse_paths = 0u, tl_starved = 0u, tl_live_at_dry = ~0u;
     uint32_t tl_deepest = 0u;            // (per lane) deepest path finished after dry
     unsigned long long tl_deep_end = 0ull;  // (per lane) when the last path of 40+ segments finished
@@ -2957,6 +2962,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                             break;
                         }
                     }
+                    TL_MARK(tl_first_pool);
                     // virtual index of queue pool_xcd -> position in the chunk sequence -> chunk -> pixel of the tile
                     const uint32_t seq = (pool_next / kChunkPix) * 8u + pool_xcd;
                     if (seq != cur_seq) {  // (wave-uniform: one scalar load per chunk entered)
@@ -3067,6 +3073,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                         }
                         return true;
                     });
+                    TL_MARK(tl_first_out);
                     if (granted == 0u) break;  // queues dry, or all accumulator entries in use (then paths are in flight)
                     // (cold: the camera, the frame's size and seed, the cone test's margins -- read once per pass; what the per-segment code
                     // keeps in registers anyway comes from there)
@@ -3085,6 +3092,7 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
                     }
                     if constexpr (kWaveCounts) wave_paths += granted;
                     DBG_ADD(dbg_pass[7], lane == 0u ? DBG_STAMP() - tp0 : 0ull);  // camera_path
+                    TL_MARK(tl_first_rays);
                     float pb;
                     int pb_i;
                     uint32_t pb_o;
@@ -3403,6 +3411,16 @@ void path_persistent_kernel(PathArgs a, PersistArgs g) {
             atomicAdd(&a.counters->tl_hist[k][b > 63ull ? 63ull : b], 1u);
         }
         atomicMax(&a.counters->tl_tail_iters_max, tl_tail_iters);
+        // start of the frame: entry -> scene staged and barrier passed -> first pool fetched -> first hand_out done -> first camera rays made
+        atomicAdd(&a.counters->tl_start_sum[0], tl_start - tl_entry);
+        atomicMax(&a.counters->tl_start_max[0], static_cast<unsigned int>(tl_start - tl_entry));
+        if (tl_first_rays != 0ull) {
+            atomicAdd(&a.counters->tl_start_sum[1], tl_first_rays - tl_start);
+            atomicMax(&a.counters->tl_start_max[1], static_cast<unsigned int>(tl_first_rays - tl_start));
+            atomicAdd(&a.counters->tl_start_sum[2], 1ull);
+            atomicAdd(&a.counters->tl_start_sum[3], tl_first_pool - tl_start);
+            atomicAdd(&a.counters->tl_start_sum[4], tl_first_out - tl_start);
+        }
         atomicAdd(&a.counters->tl_starved_sum, static_cast<unsigned long long>(tl_starved));
         atomicMax(&a.counters->tl_starved_max, tl_starved);
         if (tl_live_at_dry != ~0u) {
