@@ -3,7 +3,7 @@
 cd /root/repo
 O=gpurun_out; P=profiles
 for f in gpu_tests all_configs tile_timing dbg_counters timeline inflight scene_size_sweep ch_bandwidth_plain; do cp $O/r05_$f.txt $P/r05_$f.txt; done
-sed -i '/amdgpu.ids/d' $P/r05_*.txt
+for f in gpu_tests all_configs tile_timing dbg_counters timeline inflight scene_size_sweep ch_bandwidth_plain; do sed -i '/amdgpu.ids/d' $P/r05_$f.txt; done
 sed -i '1i cover scenes of growing size at 1200x800x32spp (tools/grid_stats.py, the knobs build for RTIOW_DEBUG_LAUNCH: what launch_path chose)' $P/r05_scene_size_sweep.txt
 for f in default three_400x225_100spp cover_1200x800_500spp cover4096_3840x2160_1024spp; do cp $O/r05_bench_$f.json $P/r05_bench_$f.json; done
 grep '^{"metric"' $O/r05_bench_2rank_gloo_rehearsal_one_gpu.json > $P/r05_bench_2rank_gloo_rehearsal_one_gpu.json
