@@ -156,6 +156,30 @@ def test_rays_from_outside_the_box_range(gpu_ctx, oracle, n):
         assert st.sphere_tests < st.segments * max(16, n // 6), (n, st.sphere_tests / st.segments)
 
 
+@pytest.mark.parametrize("grid", [34, 36, 38, 39])
+def test_scenes_whose_lists_leave_room_for_fewer_waves(gpu_ctx, oracle, grid):
+    """Cover scenes of 4625 / 5185 / 5778 / 6086 spheres: the lists take 91 - 118 KB of a CU's LDS and launch_path sizes the workgroup wave by
+    wave -- 1024, 896, 704, 640 threads (round 5; groups of 14, 11 and 10 waves are no multiple of the four SIMDs).  The clustered list, with
+    and without the primary pass forced, as one dispatch and as two row tiles, against the flat list, and rows of it against the oracle."""
+    sph, mat = V.make_cover_scene(1, grid)
+    w, h = 96, 48
+    cam = V.make_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, w / h, 0.1, 10.0)
+    base = dict(spp=12, max_depth=12, seed=5)
+    gpu_ctx.set_scene(sph, mat)
+    flat = gpu_ctx.render(cam, V.make_params(w, h, kernel=V.KERNEL_PERSISTENT, **base))
+    segs = gpu_ctx.stats().segments
+    # (the oracle, brute force over ~6000 spheres: a quarter of the rows)
+    want_rows, _ = oracle.render(sph, mat, cam, V.make_params(w, h, row_block=4, tile_rank=1, tile_count=4, **base))
+    assert np.array_equal(flat[np.array([y for y in range(h) if (y // 4) % 4 == 1])], want_rows)
+    for kernel in (V.KERNEL_CLUSTERED, V.KERNEL_CLUSTERED_PASS):
+        got = gpu_ctx.render(cam, V.make_params(w, h, kernel=kernel, **base))
+        assert gpu_ctx.last_kernel() == V.KERNEL_CLUSTERED
+        assert np.array_equal(got, flat) and gpu_ctx.stats().segments == segs
+        tiles = [gpu_ctx.render(cam, V.make_params(w, h, kernel=kernel, row_block=4, tile_rank=r, tile_count=2, **base)) for r in range(2)]
+        for r in range(2):
+            assert np.array_equal(tiles[r], flat[np.array([y for y in range(h) if (y // 4) % 2 == r])])
+
+
 @pytest.mark.parametrize("n", [700, 2500])
 def test_many_samples_per_pixel_on_a_large_scene(gpu_ctx, oracle, n):
     """Many samples per pixel on a scene of the large-scene kernels (super-clusters from 40 clusters on: both sizes have them):
